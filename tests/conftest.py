@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gold_dir():
+    return GOLD
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement (test infrastructure). Built on demand with gcc."""
+    from oracle import oracle as O
+    O.lib()
+    return O
