@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X sDTW alignment stage on the BASELINE.json headline configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (config.workload = "ncov_r9_dna_q250", BASELINE.json configs[2]): synthetic R9 DNA reads (250 events,
+5 % shorter) against the 29 903 b nCoV-2019 reference, both strands, -q 250.  A "step" is one pass of the hot
+path (sfa_align_batch_device: plan + fill kernels + finalize kernel) over one batch of --reads reads per GPU whose
+query events are already resident in HBM, plus (N > 1) the gather of result rows to rank 0 over RCCL.  Reads shard
+across ranks with no data-path collective (weak scaling: every rank gets --reads reads); the reference event model
+is broadcast once, before the timed region.
+
+The JSON line also carries
+  roofline      HBM roofline of the dominant kernel (sdtw_fill_kernel): algorithmic bytes per launch / its mean
+                duration, measured with HIP events on the stream the kernel is launched on; plus the VALU view
+                (cells/s vs lanes*clock/ops_per_cell), which is the bound that actually bites.
+  cpu_baseline  the oracle (CPU restatement of the reference algorithm, pthread fan-out) timed on this box's host
+                cores on a bounded sample of the same workload; kind "port".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU per step")
+    ap.add_argument("--workload", default="ncov_r9_dna_q250")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import sigfish_amd as S
+    from sigfish_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- reference event model: built on rank 0, broadcast over RCCL/xGMI, resident in every rank's HBM ----
+    if rank == 0:
+        ref, flag, _, _, _ = synth.workload(args.workload, n_reads=8, seed=0)
+    if world > 1:
+        hdr = torch.zeros(4, dtype=torch.int64, device=dev)
+        if rank == 0:
+            rna = ref.reverse is None
+            hdr[:] = torch.tensor([ref.num_ref, int(ref.ref_lengths.sum()), int(rna), flag])
+        dist.broadcast(hdr, 0)
+        num_ref, total, rna, flag = (int(x) for x in hdr.tolist())
+        meta_t = torch.zeros(3 * num_ref, dtype=torch.int32, device=dev)
+        lev_t = torch.zeros(total * (1 if rna else 2), dtype=torch.float32, device=dev)
+        if rank == 0:
+            meta_t[:] = torch.from_numpy(np.concatenate([ref.ref_lengths, ref.st_offset, ref.seq_lengths]))
+            flat = np.concatenate(ref.forward + ([] if rna else ref.reverse))
+            lev_t[:] = torch.from_numpy(flat)
+        dist.broadcast(meta_t, 0)
+        dist.broadcast(lev_t, 0)
+        if rank != 0:
+            m = meta_t.cpu().numpy()
+            lens, offs, seql = m[:num_ref], m[num_ref:2 * num_ref], m[2 * num_ref:]
+            lv = lev_t.cpu().numpy()
+            cuts = np.concatenate([[0], np.cumsum(lens)])
+            fw = [lv[cuts[i]:cuts[i + 1]] for i in range(num_ref)]
+            rv = None if rna else [lv[total + cuts[i]:total + cuts[i + 1]] for i in range(num_ref)]
+            ref = S.RefModel([f"contig{i}" for i in range(num_ref)], seql, lens, offs, fw, rv)
+    al = S.Aligner(ref, flag, device=local_rank)
+
+    # ---- this rank's shard of reads: synthetic, generated here, uploaded to HBM before the timed region ----
+    q, q_off, _ = synth.make_reads(ref, args.reads, qlen=250, seed=1000 + rank)
+    n = args.reads
+    lens = q_off[1:] - q_off[:-1]
+    strands = 1 if ref.reverse is None else 2
+    cols = int(ref.ref_lengths.sum()) * strands
+    cells = int(lens.sum()) * cols
+    alg_bytes = int((4 * lens + 4 * cols + 32).sum())
+    d_q = torch.from_numpy(q).to(dev)
+    d_out = torch.zeros(n * S.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros_like(d_out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+
+    fill_ms, launches = [], 0
+
+    def step(record):
+        nonlocal launches
+        al.align_db_device(d_q.data_ptr(), q_off, n, d_out.data_ptr(), sync=True)
+        if record:
+            p = al.profile()
+            fill_ms.append(p["fill_ms"])
+            launches += p["fill_launches"]
+        if world > 1:  # final gather of the result rows (24 B/read) to rank 0
+            dist.gather(d_out, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        al.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_reads = n * world * args.steps
+    value = total_reads / elapsed
+    kern_s = (sum(fill_ms) / max(len(fill_ms), 1)) / 1e3  # mean fill time per step (all fill launches of a step)
+    launches_per_step = max(launches // max(args.steps, 1), 1)
+    achieved = alg_bytes / kern_s / 1e9
+    cells_per_s_kernel = cells / kern_s
+    ops_per_cell = 7.75  # counted from the shipped R=16 ISA: 7 per cell + ~12 per 16-cell step
+    out = {
+        "metric": "reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)",
+        "value": round(value, 1),
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "reads_per_gpu": n, "query_events": 250, "ref_kmers": int(ref.ref_lengths.sum()),
+                   "strands": strands, "sharding": f"reads x{world}", "cells_per_read_full": 250 * cols},
+        "dp_cells_per_s": round(cells * world * args.steps / elapsed, 1),
+        "roofline": {
+            "bound": "hbm", "kernel": "sdtw_fill_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+            "algorithmic_bytes_per_step": alg_bytes, "fill_launches_per_step": launches_per_step,
+            "kernel_ms_per_step": round(kern_s * 1e3, 3),
+            "valu": {"cells_per_s": round(cells_per_s_kernel, 1), "ops_per_cell": ops_per_cell,
+                     "peak_cells_per_s": round(VALU_LANE_OPS / ops_per_cell, 1),
+                     "frac": round(cells_per_s_kernel * ops_per_cell / VALU_LANE_OPS, 4)},
+        },
+    }
+
+    # ---- CPU baseline: the oracle on a bounded sample of this rank's reads, all host cores -----------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O  # checker / baseline only
+        cores = os.cpu_count() or 1
+        oref = O.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
+        pilot = min(n, cores * 2)
+        t1 = time.perf_counter()
+        O.align_batch(q, q_off[:pilot + 1], oref, flag, threads=cores)
+        rate = pilot / (time.perf_counter() - t1)
+        sample = int(max(pilot, min(n, rate * args.cpu_seconds)))
+        t1 = time.perf_counter()
+        want = O.align_batch(q, q_off[:sample + 1], oref, flag, threads=cores)
+        dt = time.perf_counter() - t1
+        got = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=S.RESULT_DTYPE)[:sample]
+        out["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "reads/s", "cores": cores, "kind": "port",
+                               "sample": f"first {sample} reads of the same batch, {dt:.1f} s wall, "
+                                         f"{int(lens[:sample].sum()) * cols / dt:.3e} cells/s",
+                               "parity_on_sample": bool(got.tobytes() == want.tobytes())}
+        out["speedup_vs_cpu_baseline"] = round(value / (sample / dt), 1)
+    al.close()
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/* sigfish_amd.h -- C-ABI of the MI355X-native sDTW alignment stage.
+ *
+ * Drop-in boundary for the reference's accelerator hook (all citations relative to hasindu2008/sigfish v0.2.0):
+ *
+ *   reference site                                   this library
+ *   -----------------------------------------------  -----------------------------------------------
+ *   init slot      src/sigfish.c:200-204 (HAVE_ACC)  sfa_init()          upload reference event arrays
+ *   align_db()     src/sigfish.c:1003-1015           sfa_align_events()  whole batch, after normalise stage
+ *                                                    sfa_align_batch()   same, packed SoA queries
+ *   teardown slot  src/sigfish.c:221-225             sfa_destroy()
+ *
+ * Plain C types only (no torch / HIP types); every pointer is caller-owned unless stated.  All functions return
+ * 0 on success, a negative SFA_E* code otherwise; sfa_last_error() gives the message.  Nothing here falls back to
+ * a CPU implementation: without a usable gfx950 device sfa_init() fails.
+ */
+#ifndef SIGFISH_AMD_H
+#define SIGFISH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFA_VERSION "0.1.0"
+
+/* option bits: numerically identical to the reference's opt.flag (src/sigfish.h:30-39) so that a host can pass
+ * core->opt.flag straight through.  Bits not listed are ignored. */
+#define SFA_RNA 0x001 /* SIGFISH_RNA: single strand, query reversed (src/sigfish.c:860-866) */
+#define SFA_DTW 0x002 /* SIGFISH_DTW: --dtw-std, standard DTW instead of subsequence (src/sigfish.c:914-917) */
+#define SFA_INV 0x004 /* SIGFISH_INV: --invert, query NOT reversed for RNA */
+#define SFA_REF 0x010 /* SIGFISH_REF: --full-ref (only affects how the caller built the reference arrays) */
+#define SFA_END 0x020 /* SIGFISH_END: --from-end (only affects which events the caller hands over) */
+
+enum {
+    SFA_OK = 0,
+    SFA_EINVAL = -1,  /* bad argument */
+    SFA_ENODEV = -2,  /* no usable GPU / HIP error */
+    SFA_ENOMEM = -3,  /* allocation failed */
+    SFA_ERANGE = -4,  /* query longer than SFA_MAX_QUERY */
+    SFA_EKERNEL = -5  /* kernel launch or execution failed */
+};
+
+#define SFA_MAX_QUERY 512 /* longest query (events) a single read may have */
+
+/* Reference event model: the fields of refsynth_t (src/sigfish.h:90-99) the alignment stage reads. */
+typedef struct {
+    int32_t num_ref;
+    const int32_t *ref_lengths;   /* [num_ref] k-mer counts (ref->ref_lengths) */
+    const int32_t *ref_st_offset; /* [num_ref] (ref->ref_st_offset) */
+    const float *const *forward;  /* [num_ref][ref_lengths[i]] z-normalised expected levels */
+    const float *const *reverse;  /* same for the reverse complement; NULL when SFA_RNA */
+} sfa_ref_t;
+
+/* One result row per read: the fields of aln_t (src/sigfish.h:146-158) that output formatting consumes. */
+typedef struct {
+    int32_t rid;     /* contig index, -1 if nothing aligned */
+    int32_t pos_st;  /* after strand flip and ref_st_offset (src/sigfish.c:971-975) */
+    int32_t pos_end;
+    float score;     /* best   (d1) */
+    float score2;    /* second (d2), +inf when there was a single candidate */
+    int8_t strand;   /* '+' or '-' */
+    uint8_t mapq;    /* src/sigfish.c:979-983 */
+    uint8_t valid;   /* 0: read skipped (no events) -- the reference prints nothing for it */
+    uint8_t pad;
+} sfa_result_t;
+
+/* The event record the reference batches hold (event_t, src/sigfish.h:57-64); used by sfa_align_events. */
+typedef struct {
+    uint64_t start;
+    float length;
+    float mean;
+    float stdv;
+} sfa_event_t;
+
+typedef struct sfa_ctx sfa_ctx_t;
+
+/* Device-side timing of the last call (HIP events recorded on the stream the kernels run on). */
+typedef struct {
+    double fill_ms;      /* DP fill kernels (the dominant kernels) */
+    double finalize_ms;  /* per-read reduction / row assembly */
+    double total_ms;     /* first kernel start -> last kernel end */
+    int64_t cells;       /* DP cells evaluated by the fill kernels, algorithmic (no padding) */
+    int64_t fill_launches;
+} sfa_profile_t;
+
+/* Create a context on HIP device `device`, copy the reference event arrays into HBM.
+ * flag: SFA_* bits.  The arrays behind `ref` may be freed after the call returns. */
+int sfa_init(sfa_ctx_t **ctx, const sfa_ref_t *ref, uint32_t flag, int device);
+
+/* Align a batch.  queries: concatenated, already z-normalised event means in EVENT order (the library applies
+ * the RNA reversal of src/sigfish.c:860-866 itself); q_off[n_reads+1] offsets into queries; a read with
+ * q_off[i+1]==q_off[i] is skipped (valid=0).  out[n_reads] is written in input order.  Blocking. */
+int sfa_align_batch(sfa_ctx_t *ctx, const float *queries, const int64_t *q_off, int32_t n_reads, sfa_result_t *out);
+
+/* Same with queries and results resident in device memory (d_queries: floats in HBM, d_out: n_reads rows in
+ * HBM); q_off stays a HOST array.  Work is enqueued on the context stream; returns after enqueueing unless
+ * `sync` is non-zero. */
+int sfa_align_batch_device(sfa_ctx_t *ctx, const float *d_queries, const int64_t *q_off, int32_t n_reads,
+                           sfa_result_t *d_out, int sync);
+
+/* align_db() shaped entry: per-read event tables exactly as db_t holds them (src/sigfish.h:177-178):
+ * events[i] -> sfa_event_t array of read i, qstart[i]/qend[i] the window chosen by normalise_single
+ * (src/sigfish.c:479-480); reads with n_events[i]==0 are skipped. */
+int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int64_t *n_events,
+                     const int64_t *qstart, const int64_t *qend, int32_t n_reads, sfa_result_t *out);
+
+/* Block until everything enqueued on the context stream has finished. */
+int sfa_sync(sfa_ctx_t *ctx);
+
+/* Timing of the most recent align call (valid after it completed / after sfa_sync). */
+int sfa_get_profile(sfa_ctx_t *ctx, sfa_profile_t *prof);
+
+/* The HIP stream (hipStream_t) the context enqueues on, as an opaque pointer. */
+void *sfa_stream(sfa_ctx_t *ctx);
+
+void sfa_destroy(sfa_ctx_t *ctx);
+
+const char *sfa_last_error(void);
+const char *sfa_version(void);
+
+/* ---- host-side helpers on the same path (no GPU needed) ------------------------------------------------ */
+
+/* Reference event model from sequences (gen_ref, src/genref.c:86-241), one record at a time.
+ * level_mean[4^k]: k-mer model means.  fwd/rev must hold (len+1-k) floats (rev may be NULL for RNA).
+ * Returns the k-mer count ref_len (or <0 on error) and stores ref_st_offset. */
+int32_t sfa_gen_ref_record(const char *seq, int32_t len, const float *level_mean, uint32_t k, uint32_t flag,
+                           int32_t query_size, float *fwd, float *rev, int32_t *st_offset);
+
+/* z-normalisation used for both queries and reference arrays (src/sigfish.c:483-502, src/genref.c:23-47). */
+void sfa_znormalise(float *v, uint64_t n);
+
+/* One PAF line for a result row (paf_str, src/sigfish.c:628-660).  Returns bytes written (excluding NUL),
+ * or a negative value if cap is too small. */
+int sfa_paf_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname,
+                uint64_t start_raw_idx, uint64_t end_raw_idx, uint64_t query_size, uint64_t len_raw_signal,
+                uint64_t rlength);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGFISH_AMD_H */

@@ -1,0 +1,71 @@
+"""ctypes loader for sigfish_amd/lib/libsigfish_amd.so (the C-ABI in include/sigfish_amd.h)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsigfish_amd.so")
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+
+class SfaRef(C.Structure):
+    _fields_ = [("num_ref", C.c_int32), ("ref_lengths", i32p), ("ref_st_offset", i32p),
+                ("forward", C.POINTER(f32p)), ("reverse", C.POINTER(f32p))]
+
+
+class SfaResult(C.Structure):
+    _fields_ = [("rid", C.c_int32), ("pos_st", C.c_int32), ("pos_end", C.c_int32), ("score", C.c_float),
+                ("score2", C.c_float), ("strand", C.c_int8), ("mapq", C.c_uint8), ("valid", C.c_uint8),
+                ("pad", C.c_uint8)]
+
+
+class SfaProfile(C.Structure):
+    _fields_ = [("fill_ms", C.c_double), ("finalize_ms", C.c_double), ("total_ms", C.c_double),
+                ("cells", C.c_int64), ("fill_launches", C.c_int64)]
+
+
+class SfaEvent(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float)]
+
+
+# every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_sync",
+           "sfa_get_profile", "sfa_stream", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
+           "sfa_znormalise", "sfa_paf_row"]
+
+_lib = None
+
+
+def load():
+    """Load the native library; fails loudly when it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C sigfish_amd/csrc` "
+                          "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.sfa_init.argtypes = [C.POINTER(vp), C.POINTER(SfaRef), C.c_uint32, C.c_int]
+    L.sfa_align_batch.argtypes = [vp, f32p, i64p, C.c_int32, vp]
+    L.sfa_align_batch_device.argtypes = [vp, vp, i64p, C.c_int32, vp, C.c_int]
+    L.sfa_align_events.argtypes = [vp, C.POINTER(C.POINTER(SfaEvent)), i64p, i64p, i64p, C.c_int32, vp]
+    L.sfa_sync.argtypes = [vp]
+    L.sfa_get_profile.argtypes = [vp, C.POINTER(SfaProfile)]
+    L.sfa_stream.argtypes = [vp]
+    L.sfa_stream.restype = vp
+    L.sfa_destroy.argtypes = [vp]
+    L.sfa_destroy.restype = None
+    L.sfa_last_error.restype = C.c_char_p
+    L.sfa_version.restype = C.c_char_p
+    L.sfa_gen_ref_record.argtypes = [C.c_char_p, C.c_int32, f32p, C.c_uint32, C.c_uint32, C.c_int32, f32p, f32p,
+                                     i32p]
+    L.sfa_gen_ref_record.restype = C.c_int32
+    L.sfa_znormalise.argtypes = [f32p, C.c_uint64]
+    L.sfa_znormalise.restype = None
+    L.sfa_paf_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(SfaResult), C.c_char_p, C.c_char_p, C.c_uint64,
+                              C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    _lib = L
+    return L

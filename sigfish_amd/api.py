@@ -1,0 +1,216 @@
+"""Host-side mirror of the reference's interface for the alignment stage, over the C-ABI.
+
+Names follow the reference (hasindu2008/sigfish v0.2.0): a RefModel is refsynth_t (src/sigfish.h:90-99) as
+produced by gen_ref (src/genref.c:86-241); Aligner.align_db is align_db (src/sigfish.c:1003-1015) for a whole
+batch; result rows carry the aln_t fields (src/sigfish.h:146-158) the PAF writer (src/sigfish.c:628-660) prints.
+"""
+import ctypes as C
+import gzip
+
+import numpy as np
+
+from . import _lib
+
+# opt.flag bits (src/sigfish.h:30-39)
+RNA, DTW, INV, REF, END = 0x001, 0x002, 0x004, 0x010, 0x020
+
+RESULT_DTYPE = np.dtype([("rid", "<i4"), ("pos_st", "<i4"), ("pos_end", "<i4"), ("score", "<f4"), ("score2", "<f4"),
+                         ("strand", "i1"), ("mapq", "u1"), ("valid", "u1"), ("pad", "u1")])
+assert RESULT_DTYPE.itemsize == C.sizeof(_lib.SfaResult)
+
+
+class SfaError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SfaError(f"{what} failed ({rc}): {_lib.load().sfa_last_error().decode()}")
+
+
+def version():
+    return _lib.load().sfa_version().decode()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def znormalise(v):
+    v = _f32(v).copy()
+    _lib.load().sfa_znormalise(v.ctypes.data_as(_lib.f32p), len(v))
+    return v
+
+
+def read_fasta(path):
+    """[(name, sequence)]: name is the first word of the header, sequence lines are concatenated (kseq.h)."""
+    op = gzip.open if str(path).endswith(".gz") else open
+    recs, name, chunks = [], None, []
+    with op(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    recs.append((name, "".join(chunks)))
+                w = line[1:].split()
+                name, chunks = (w[0] if w else ""), []
+            elif name is not None:
+                chunks.append("".join(line.split()))
+    if name is not None:
+        recs.append((name, "".join(chunks)))
+    return recs
+
+
+class RefModel:
+    """refsynth_t: per-contig z-normalised expected event levels, forward and (DNA) reverse complement."""
+
+    def __init__(self, names, seq_lengths, ref_lengths, st_offset, forward, reverse):
+        self.names = list(names)
+        self.seq_lengths = np.asarray(seq_lengths, np.int32)
+        self.ref_lengths = np.ascontiguousarray(ref_lengths, np.int32)
+        self.st_offset = np.ascontiguousarray(st_offset, np.int32)
+        self.forward = [_f32(a) for a in forward]
+        self.reverse = None if reverse is None else [_f32(a) for a in reverse]
+        self.num_ref = len(self.names)
+
+    @classmethod
+    def from_records(cls, records, level_mean, k, flag=0, query_size=250):
+        """gen_ref (src/genref.c:86-241) over [(name, sequence)] with a 4^k table of k-mer level means."""
+        L = _lib.load()
+        lv = _f32(level_mean)
+        if len(lv) != 4 ** k:
+            raise ValueError(f"k-mer model needs {4 ** k} levels, got {len(lv)}")
+        rna = bool(flag & RNA)
+        names, sl, rl, so, fw, rv = [], [], [], [], [], []
+        for name, seq in records:
+            b = seq.encode()
+            cap = max(len(b) + 1 - k, 1)
+            f = np.zeros(cap, np.float32)
+            r = np.zeros(cap, np.float32)
+            off = C.c_int32(0)
+            n = L.sfa_gen_ref_record(b, len(b), lv.ctypes.data_as(_lib.f32p), k, flag, query_size,
+                                     f.ctypes.data_as(_lib.f32p), None if rna else r.ctypes.data_as(_lib.f32p),
+                                     C.byref(off))
+            if n <= 0:
+                raise SfaError(f"contig {name}: cannot build reference events (length {len(b)}, k={k})")
+            names.append(name)
+            sl.append(len(b))
+            rl.append(n)
+            so.append(off.value)
+            fw.append(f[:n].copy())
+            rv.append(r[:n].copy())
+        return cls(names, sl, rl, so, fw, None if rna else rv)
+
+    @classmethod
+    def from_fasta(cls, path, level_mean, k, flag=0, query_size=250):
+        return cls.from_records(read_fasta(path), level_mean, k, flag, query_size)
+
+    def total_columns(self):
+        return int(self.ref_lengths.sum()) * (1 if self.reverse is None else 2)
+
+    def _as_c(self):
+        n = self.num_ref
+        fa = (_lib.f32p * n)(*[a.ctypes.data_as(_lib.f32p) for a in self.forward])
+        ra = None
+        if self.reverse is not None:
+            ra = (_lib.f32p * n)(*[a.ctypes.data_as(_lib.f32p) for a in self.reverse])
+        ref = _lib.SfaRef(n, self.ref_lengths.ctypes.data_as(_lib.i32p), self.st_offset.ctypes.data_as(_lib.i32p),
+                          fa, C.cast(ra, C.POINTER(_lib.f32p)) if ra is not None else None)
+        return ref, (fa, ra)
+
+
+class Aligner:
+    """The accelerator context: reference arrays resident in HBM, batches aligned by the gfx950 kernels."""
+
+    def __init__(self, ref: RefModel, flag=0, device=0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        self.ref, self.flag, self.device = ref, int(flag), int(device)
+        cref, keep = ref._as_c()
+        _check(self._L.sfa_init(C.byref(self._h), C.byref(cref), self.flag, self.device), "sfa_init")
+        del keep
+
+    def close(self):
+        if self._h:
+            self._L.sfa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- align_db over packed host arrays -------------------------------------------------------------------
+    def align_db(self, queries, q_off):
+        """queries: concatenated z-normalised event means (event order); q_off: int64[n+1]. -> RESULT_DTYPE[n]"""
+        q = _f32(queries)
+        qo = np.ascontiguousarray(q_off, np.int64)
+        n = len(qo) - 1
+        out = np.zeros(n, RESULT_DTYPE)
+        if q.size == 0:
+            q = np.zeros(1, np.float32)
+        _check(self._L.sfa_align_batch(self._h, q.ctypes.data_as(_lib.f32p), qo.ctypes.data_as(_lib.i64p), n,
+                                       out.ctypes.data_as(C.c_void_p)), "sfa_align_batch")
+        return out
+
+    # -- same with device-resident buffers (torch tensors or raw pointers) ------------------------------------
+    def align_db_device(self, d_queries_ptr, q_off, n, d_out_ptr, sync=True):
+        qo = np.ascontiguousarray(q_off, np.int64)
+        _check(self._L.sfa_align_batch_device(self._h, C.c_void_p(d_queries_ptr), qo.ctypes.data_as(_lib.i64p), n,
+                                              C.c_void_p(d_out_ptr), 1 if sync else 0), "sfa_align_batch_device")
+
+    def align_events(self, event_tables, qstart, qend):
+        """event_tables: list of structured arrays with sfa_event_t layout (or None)."""
+        n = len(event_tables)
+        EP = C.POINTER(_lib.SfaEvent)
+        ptrs = (EP * n)()
+        nev = np.zeros(n, np.int64)
+        keep = []
+        for i, t in enumerate(event_tables):
+            if t is None or len(t) == 0:
+                ptrs[i] = None
+                continue
+            a = np.ascontiguousarray(t)
+            keep.append(a)
+            ptrs[i] = C.cast(a.ctypes.data, EP)
+            nev[i] = len(a)
+        qs = np.ascontiguousarray(qstart, np.int64)
+        qe = np.ascontiguousarray(qend, np.int64)
+        out = np.zeros(n, RESULT_DTYPE)
+        _check(self._L.sfa_align_events(self._h, ptrs, nev.ctypes.data_as(_lib.i64p), qs.ctypes.data_as(_lib.i64p),
+                                        qe.ctypes.data_as(_lib.i64p), n, out.ctypes.data_as(C.c_void_p)),
+               "sfa_align_events")
+        return out
+
+    def sync(self):
+        _check(self._L.sfa_sync(self._h), "sfa_sync")
+
+    def profile(self):
+        p = _lib.SfaProfile()
+        _check(self._L.sfa_get_profile(self._h, C.byref(p)), "sfa_get_profile")
+        return dict(fill_ms=p.fill_ms, finalize_ms=p.finalize_ms, total_ms=p.total_ms, cells=p.cells,
+                    fill_launches=p.fill_launches)
+
+    def stream(self):
+        return self._L.sfa_stream(self._h)
+
+
+EVENT_DTYPE = np.dtype([("start", "<u8"), ("length", "<f4"), ("mean", "<f4"), ("stdv", "<f4")], align=True)
+
+
+def paf_row(res, read_id, rname, start_raw, end_raw, query_size, len_raw, rlength):
+    """paf_str (src/sigfish.c:628-660) for one result row."""
+    r = _lib.SfaResult(int(res["rid"]), int(res["pos_st"]), int(res["pos_end"]), float(res["score"]),
+                       float(res["score2"]), int(res["strand"]), int(res["mapq"]), int(res["valid"]), 0)
+    buf = C.create_string_buffer(4096)
+    n = _lib.load().sfa_paf_row(buf, 4096, C.byref(r), str(read_id).encode(), str(rname).encode(), int(start_raw),
+                                int(end_raw), int(query_size), int(len_raw), int(rlength))
+    if n < 0:
+        raise SfaError("sfa_paf_row: buffer too small")
+    return buf.raw[:n].decode()

@@ -1,0 +1,120 @@
+// sfa_host.cpp -- host-side pieces of the alignment path that stay on the CPU so that the numbers fed to and
+// read from the GPU are bit-identical to the reference's: reference-event-model synthesis, z-normalisation and
+// PAF row formatting.  Plain C++ (no HIP); compiled with -ffp-contract=off.
+//
+// reference: hasindu2008/sigfish v0.2.0 -- src/genref.c:23-47,86-241, src/ref.h:13-77, src/sigfish.c:483-502,
+// 628-660.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sigfish_amd.h"
+
+namespace {
+
+// 2-bit code of a base; anything outside ACGT/acgt ranks as 'A' (src/ref.h:13-26)
+inline uint32_t code_of(unsigned char b) {
+    static const struct Table {
+        uint8_t t[256];
+        Table() {
+            memset(t, 0, sizeof t);
+            t['C'] = t['c'] = 1;
+            t['G'] = t['g'] = 2;
+            t['T'] = t['t'] = 3;
+        }
+    } tab;
+    return tab.t[b];
+}
+
+// code of the complement as the reference builds it: A<->T, C<->G, everything else -> 'T' (src/ref.h:43-68)
+inline uint32_t comp_code_of(unsigned char b) {
+    switch (b) {
+        case 'A': case 'a': return 3;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 1;
+        case 'T': case 't': return 0;
+        default: return 3;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void sfa_znormalise(float *v, uint64_t n) {
+    // sequential fp32 accumulation, population variance, sqrt in double (src/genref.c:23-47)
+    const float count = static_cast<float>(n);
+    float mean = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) mean += v[i];
+    mean /= count;
+    float var = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) {
+        const float d = v[i] - mean;
+        var += d * d;
+    }
+    var /= count;
+    const float sd = static_cast<float>(std::sqrt(static_cast<double>(var)));
+    for (uint64_t i = 0; i < n; ++i) v[i] = (v[i] - mean) / sd;
+}
+
+int32_t sfa_gen_ref_record(const char *seq, int32_t len, const float *level_mean, uint32_t k, uint32_t flag,
+                           int32_t query_size, float *fwd, float *rev, int32_t *st_offset) {
+    if (!seq || !level_mean || !fwd || k == 0 || k > 9 || len < static_cast<int32_t>(k)) return -1;
+    const bool rna = (flag & SFA_RNA) != 0;
+    if (!rna && !rev) return -1;
+    const int32_t full = len + 1 - static_cast<int32_t>(k);
+    int32_t n = full;
+    if (rna && !(flag & SFA_REF)) {  // only the 1.5*q events next to the 3' end (src/genref.c:132-135)
+        const uint32_t heu = static_cast<uint32_t>(query_size * 1.5);
+        n = heu > static_cast<uint32_t>(full) ? full : static_cast<int32_t>(heu);
+    }
+    const uint32_t mask = (k == 16) ? 0xffffffffu : ((1u << (2 * k)) - 1u);
+    int32_t off = 0;
+    // rolling k-mer rank over [begin, begin+n+k-1): rank = sum code(s[i]) * 4^(k-1-i)
+    auto roll = [&](int32_t begin, auto code_at, auto store) {
+        uint32_t r = 0;
+        for (uint32_t i = 0; i + 1 < k; ++i) r = (r << 2) | code_at(begin + static_cast<int32_t>(i));
+        for (int32_t j = 0; j < n; ++j) {
+            r = ((r << 2) | code_at(begin + j + static_cast<int32_t>(k) - 1)) & mask;
+            store(j, level_mean[r]);
+        }
+    };
+    auto fcode = [&](int32_t i) { return code_of(static_cast<unsigned char>(seq[i])); };
+    if (!rna) {
+        roll(0, fcode, [&](int32_t j, float v) { fwd[j] = v; });
+        // reverse complement read in place: rc[i] = comp(seq[len-1-i])
+        auto rcode = [&](int32_t i) { return comp_code_of(static_cast<unsigned char>(seq[len - 1 - i])); };
+        roll(0, rcode, [&](int32_t j, float v) { rev[j] = v; });
+    } else if (flag & SFA_INV) {  // src/genref.c:166-177
+        roll(len - n - (static_cast<int32_t>(k) - 1), fcode, [&](int32_t j, float v) { fwd[n - 1 - j] = v; });
+    } else if (flag & SFA_END) {  // query end maps to the 5' start of the transcript (src/genref.c:186-187)
+        roll(0, fcode, [&](int32_t j, float v) { fwd[j] = v; });
+    } else {  // 3' slice (src/genref.c:189-192)
+        off = len - n - (static_cast<int32_t>(k) - 1);
+        roll(off, fcode, [&](int32_t j, float v) { fwd[j] = v; });
+    }
+    sfa_znormalise(fwd, static_cast<uint64_t>(n));
+    if (!rna) sfa_znormalise(rev, static_cast<uint64_t>(n));
+    if (st_offset) *st_offset = off;
+    return n;
+}
+
+int sfa_paf_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname,
+                uint64_t start_raw_idx, uint64_t end_raw_idx, uint64_t query_size, uint64_t len_raw_signal,
+                uint64_t rlength) {
+    // src/sigfish.c:634-635: both in fp32; query_size converts u64 -> float
+    const float block_len = static_cast<float>(r->pos_end - r->pos_st);
+    const float prod = r->score * block_len;
+    const float residue = block_len - prod / static_cast<float>(query_size);
+    const int n = snprintf(buf, cap, "%s\t%ld\t%ld\t%ld\t%c\t%s\t%d\t%d\t%d\t%d\t%d\t%d\ttp:A:P\td1:f:%.2f\td2:f:%.2f\n", read_id,
+                           static_cast<long>(len_raw_signal), static_cast<long>(start_raw_idx), static_cast<long>(end_raw_idx),
+                           static_cast<char>(r->strand), rname, static_cast<int>(rlength), r->pos_st, r->pos_end,
+                           static_cast<int>(std::round(static_cast<double>(residue))),
+                           static_cast<int>(std::round(static_cast<double>(block_len))), static_cast<int>(r->mapq),
+                           static_cast<double>(r->score), static_cast<double>(r->score2));
+    if (n < 0 || static_cast<size_t>(n) >= cap) return -1;
+    return n;
+}
+
+}  // extern "C"

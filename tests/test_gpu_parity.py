@@ -1,0 +1,164 @@
+"""Parity tests proper: the HIP path through the C-ABI against (a) the golden fixtures produced by the compiled
+reference and (b) the oracle on seeded inputs.  Integer fields bit-exact; fp32 scores bit-exact as well (the
+north-star tolerance is 1e-4 relative; the kernels are built to hit 0)."""
+import numpy as np
+import pytest
+
+import sigfish_amd as S
+from sigfish_amd import synth
+from tests.util import case_names, load_case, paf_lines_from_results
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # stated tolerance for d1/d2; asserted at 0 ulp below
+
+
+def _oracle_ref(O, ref):
+    return O.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
+
+
+def assert_rows_equal(got, want):
+    for f in ("valid", "rid", "strand", "pos_st", "pos_end", "mapq"):
+        assert np.array_equal(got[f], want[f]), (f, np.nonzero(got[f] != want[f])[0][:10], got[f][:8], want[f][:8])
+    v = want["valid"] == 1
+    assert np.allclose(got["score"][v], want["score"][v], rtol=REL_TOL)
+    assert np.array_equal(got["score"][v].view(np.uint32), want["score"][v].view(np.uint32))
+    assert np.array_equal(got["score2"][v].view(np.uint32), want["score2"][v].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_cases(oracle, name):
+    """Fixture inputs (real reads, reference-built event arrays) -> rows and PAF text of the compiled reference."""
+    c = load_case(name)
+    ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
+    with S.Aligner(ref, c["flag"]) as al:
+        res = al.align_db(c["queries"], c["q_off"])
+    for f in ("rid", "pos_st", "pos_end", "mapq", "strand"):
+        assert np.array_equal(res[f], c[f]), (f, res[f], c[f])
+    assert np.array_equal(res["score"].view(np.uint32), c["score"].view(np.uint32))
+    assert np.array_equal(res["score2"].view(np.uint32), c["score2"].view(np.uint32))
+    if not c["sam"]:
+        lines = []
+        vi = 0
+        for i, rid in enumerate(c["read_ids"]):
+            if not c["read_valid"][i]:
+                continue
+            r = res[vi]
+            end_raw = int(c["ev_start_last"][vi]) + int(c["ev_len_last"][vi])
+            lines.append(S.paf_row(r, rid, ref.names[int(r["rid"])], int(c["ev_start_first"][vi]), end_raw,
+                                   int(c["qend"][i]) - 1 - int(c["qstart"][i]), int(c["len_raw"][i]),
+                                   int(ref.seq_lengths[int(r["rid"])])))
+            vi += 1
+        assert "".join(lines) == c["out_text"]
+
+
+@pytest.mark.parametrize("wl,n", [("ncov_r9_dna_q250", 203), ("sequin_r9_rna_q250", 64),
+                                  ("rna004_fullref_dtwstd_q250", 48)])
+def test_synthetic_vs_oracle(oracle, wl, n):
+    ref, flag, q, q_off, meta = synth.workload(wl, n_reads=n, seed=11)
+    with S.Aligner(ref, flag) as al:
+        got = al.align_db(q, q_off)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16)
+    assert_rows_equal(got, want)
+
+
+def _small_ref(rng, lens, rna, quant=False):
+    def arr(n):
+        a = (rng.integers(-6, 7, n) / 4).astype(np.float32) if quant else rng.normal(size=n).astype(np.float32)
+        return a
+    fw = [arr(n) for n in lens]
+    rv = None if rna else [arr(n) for n in lens]
+    names = [f"c{i}" for i in range(len(lens))]
+    return S.RefModel(names, [n + 5 for n in lens], lens, rng.integers(0, 3, len(lens)) if rna else [0] * len(lens),
+                      fw, rv)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
+def test_ragged_and_ties(oracle, seed, mode):
+    """Edge cases the reference's own runs exercise: ragged query lengths (incl. 1..24 and >256), empty reads,
+    contigs shorter than the query, exact ties from quantised levels, batches that do not fill a wavefront."""
+    rng = np.random.default_rng(1000 + seed)
+    rna = mode != "dna"
+    flag = {"dna": 0, "rna": S.RNA, "rna_std": S.RNA | S.DTW, "rna_inv": S.RNA | S.INV}[mode]
+    quant = seed % 2 == 0
+    lens = [int(x) for x in rng.integers(3, 900, size=int(rng.integers(1, 9)))]
+    if seed == 3:
+        lens = [1, 2, 700]
+    ref = _small_ref(rng, lens, rna, quant)
+    n = int(rng.integers(1, 40))
+    qlens = rng.choice([0, 1, 2, 7, 25, 63, 64, 65, 100, 128, 129, 250, 256, 257, 300, 512], size=n)
+    if seed == 5:
+        qlens[:] = 250
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = (rng.integers(-6, 7, int(q_off[-1])) / 4).astype(np.float32) if quant else rng.normal(size=int(q_off[-1])).astype(np.float32)
+    with S.Aligner(ref, flag) as al:
+        got = al.align_db(q, q_off)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=8)
+    assert_rows_equal(got, want)
+
+
+def test_align_events_entry(oracle):
+    """align_db-shaped entry: AoS event tables + qstart/qend, as db_t holds them."""
+    from sigfish_amd.api import EVENT_DTYPE
+    rng = np.random.default_rng(5)
+    ref = _small_ref(rng, [400, 90], False)
+    tables, qs, qe, flat = [], [], [], []
+    for i in range(9):
+        ne = int(rng.integers(0, 400)) if i != 4 else 0
+        t = np.zeros(ne, EVENT_DTYPE)
+        t["mean"] = rng.normal(size=ne)
+        t["start"] = np.arange(ne) * 7
+        t["length"] = 7
+        a = min(50, ne)
+        b = min(a + 250, ne)
+        tables.append(t if ne else None)
+        qs.append(a)
+        qe.append(b)
+        flat.append(t["mean"][a:b].astype(np.float32) if ne else np.zeros(0, np.float32))
+    with S.Aligner(ref, 0) as al:
+        got = al.align_events(tables, qs, qe)
+    q_off = np.concatenate([[0], np.cumsum([len(f) for f in flat])]).astype(np.int64)
+    want = oracle.align_batch(np.concatenate(flat), q_off, _oracle_ref(oracle, ref), 0, threads=4)
+    assert_rows_equal(got, want)
+
+
+def test_full_size_properties():
+    """BASELINE config 3 at full size (100k reads x nCoV): size-independent properties instead of the oracle.
+    (1) determinism / idempotence: same batch twice -> identical rows; (2) permutation equivariance: results
+    follow their reads; (3) sub-batch consistency: a slice aligned alone equals the slice of the big batch;
+    (4) truth recovery: reads drawn from the reference map back onto their origin."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=100_000, seed=3)
+    n = meta["n_reads"]
+    with S.Aligner(ref, flag) as al:
+        a = al.align_db(q, q_off)
+        b = al.align_db(q, q_off)
+        assert a.tobytes() == b.tobytes()
+        # reversed read order
+        lens = (q_off[1:] - q_off[:-1])
+        order = np.arange(n)[::-1]
+        q2 = np.concatenate([q[q_off[i]:q_off[i + 1]] for i in order[:5000]])
+        qo2 = np.concatenate([[0], np.cumsum(lens[order[:5000]])]).astype(np.int64)
+        c = al.align_db(q2, qo2)
+        assert c.tobytes() == a[order[:5000]].tobytes()
+        d = al.align_db(q[q_off[777]:q_off[1301]], q_off[777:1302] - q_off[777])
+        assert d.tobytes() == a[777:1301].tobytes()
+    assert (a["valid"] == 1).all() and (a["mapq"] <= 60).all()
+    tr = meta["truth"]
+    strand_ok = (a["strand"] == np.where(tr["strand"] == 0, ord("+"), ord("-")))
+    rl = int(ref.ref_lengths[0])
+    exp_st = np.where(tr["strand"] == 0, tr["start"], rl - (tr["start"] + tr["span"]))
+    near = np.abs(a["pos_st"] - exp_st) <= 30
+    full = lens == 250
+    assert (strand_ok & near)[full].mean() > 0.97
+    assert (a["pos_end"] > a["pos_st"]).all()
+    assert (a["score2"] >= a["score"]).all()
+
+
+def test_no_device_fallback_is_loud():
+    ref = _small_ref(np.random.default_rng(0), [50], False)
+    with pytest.raises(S.SfaError):
+        S.Aligner(ref, 0, device=99)
+    with S.Aligner(ref, 0) as al:
+        with pytest.raises(S.SfaError):
+            al.align_db(np.zeros(600, np.float32), np.array([0, 600], np.int64))  # > SFA_MAX_QUERY
