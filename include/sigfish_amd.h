@@ -78,12 +78,29 @@ typedef struct sfa_ctx sfa_ctx_t;
 
 /* Device-side timing of the last call (HIP events recorded on the stream the kernels run on). */
 typedef struct {
-    double fill_ms;      /* DP fill kernels (the dominant kernels) */
-    double finalize_ms;  /* per-read reduction / row assembly */
-    double total_ms;     /* first kernel start -> last kernel end */
-    int64_t cells;       /* DP cells evaluated by the fill kernels, algorithmic (no padding) */
-    int64_t fill_launches;
+    double fill_ms;        /* pass 1: sdtw_fill_kernel (the dominant kernel) */
+    double trace_ms;       /* pass 2: sdtw_trace_kernel (start-column recovery of the winners) */
+    double finalize_ms;    /* per-read reductions / row assembly */
+    double total_ms;       /* first kernel start -> last kernel end */
+    int64_t cells;         /* DP cells of the batch, algorithmic: sum(qlen) * sum over (contig,strand) of rlen */
+    int64_t fill_launches; /* fill launches in the call (1) */
+    int64_t ckpt_interval; /* steps between checkpoints (0: none / single pass) */
+    int64_t ckpt_bytes;    /* HBM taken by the checkpoints of the batch */
+    int64_t n_tasks;       /* wave-tasks of the fill launch */
+    int64_t n_chunks;      /* pieces the (contig,strand) list was cut into */
 } sfa_profile_t;
+
+/* How a batch is laid out on the device (host logic only; needs no GPU). */
+typedef struct {
+    int32_t n_quads;          /* wavefronts' worth of reads: groups of <= 4 reads with the same query length */
+    int32_t n_chunks;
+    int32_t n_classes;        /* rows-per-lane classes present */
+    int32_t max_rows_per_lane;
+    int32_t ckpt_interval;
+    int32_t trace_margin;
+    int64_t ckpt_bytes;
+    int64_t n_tasks;
+} sfa_plan_info_t;
 
 /* Create a context on HIP device `device`, copy the reference event arrays into HBM.
  * flag: SFA_* bits.  The arrays behind `ref` may be freed after the call returns. */
@@ -105,6 +122,17 @@ int sfa_align_batch_device(sfa_ctx_t *ctx, const float *d_queries, const int64_t
  * (src/sigfish.c:479-480); reads with n_events[i]==0 are skipped. */
 int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int64_t *n_events,
                      const int64_t *qstart, const int64_t *qend, int32_t n_reads, sfa_result_t *out);
+
+/* Tuning knobs (all optional): "single_pass" (0/1: track start columns in one pass instead of fill + trace),
+ * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = 2*qlen),
+ * "waves_per_simd" (1..8, occupancy target used when splitting the contig list). */
+int sfa_set_option(sfa_ctx_t *ctx, const char *key, int64_t value);
+
+/* Plan a batch without running it: how reads would be grouped.  slot_of_read[n_reads] (may be NULL) receives
+ * quad*4+slot per read or -1 for skipped reads; job_len[n_jobs] are the (contig,strand) lengths in processing
+ * order.  ckpt_interval / ckpt_budget_bytes as in sfa_set_option (0 = defaults). */
+int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len, int32_t n_jobs, int64_t ckpt_interval,
+                   int64_t ckpt_budget_bytes, int32_t *slot_of_read, sfa_plan_info_t *info);
 
 /* Block until everything enqueued on the context stream has finished. */
 int sfa_sync(sfa_ctx_t *ctx);

@@ -22,8 +22,16 @@ class SfaResult(C.Structure):
 
 
 class SfaProfile(C.Structure):
-    _fields_ = [("fill_ms", C.c_double), ("finalize_ms", C.c_double), ("total_ms", C.c_double),
-                ("cells", C.c_int64), ("fill_launches", C.c_int64)]
+    _fields_ = [("fill_ms", C.c_double), ("trace_ms", C.c_double), ("finalize_ms", C.c_double),
+                ("total_ms", C.c_double), ("cells", C.c_int64), ("fill_launches", C.c_int64),
+                ("ckpt_interval", C.c_int64), ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64),
+                ("n_chunks", C.c_int64)]
+
+
+class SfaPlanInfo(C.Structure):
+    _fields_ = [("n_quads", C.c_int32), ("n_chunks", C.c_int32), ("n_classes", C.c_int32),
+                ("max_rows_per_lane", C.c_int32), ("ckpt_interval", C.c_int32), ("trace_margin", C.c_int32),
+                ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64)]
 
 
 class SfaEvent(C.Structure):
@@ -32,7 +40,7 @@ class SfaEvent(C.Structure):
 
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_sync",
-           "sfa_get_profile", "sfa_stream", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
+           "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row"]
 
 _lib = None
@@ -52,6 +60,8 @@ def load():
     L.sfa_align_batch.argtypes = [vp, f32p, i64p, C.c_int32, vp]
     L.sfa_align_batch_device.argtypes = [vp, vp, i64p, C.c_int32, vp, C.c_int]
     L.sfa_align_events.argtypes = [vp, C.POINTER(C.POINTER(SfaEvent)), i64p, i64p, i64p, C.c_int32, vp]
+    L.sfa_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sfa_plan_batch.argtypes = [i64p, C.c_int32, i32p, C.c_int32, C.c_int64, C.c_int64, i32p, C.POINTER(SfaPlanInfo)]
     L.sfa_sync.argtypes = [vp]
     L.sfa_get_profile.argtypes = [vp, C.POINTER(SfaProfile)]
     L.sfa_stream.argtypes = [vp]

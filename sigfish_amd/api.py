@@ -188,17 +188,32 @@ class Aligner:
                "sfa_align_events")
         return out
 
+    def set_option(self, key, value):
+        _check(self._L.sfa_set_option(self._h, key.encode(), int(value)), f"sfa_set_option({key})")
+
     def sync(self):
         _check(self._L.sfa_sync(self._h), "sfa_sync")
 
     def profile(self):
         p = _lib.SfaProfile()
         _check(self._L.sfa_get_profile(self._h, C.byref(p)), "sfa_get_profile")
-        return dict(fill_ms=p.fill_ms, finalize_ms=p.finalize_ms, total_ms=p.total_ms, cells=p.cells,
-                    fill_launches=p.fill_launches)
+        return {k: getattr(p, k) for k, _ in _lib.SfaProfile._fields_}
 
     def stream(self):
         return self._L.sfa_stream(self._h)
+
+
+def plan_batch(q_off, job_len, ckpt_interval=0, ckpt_budget_bytes=0):
+    """Host-side batch layout (no GPU needed): (info dict, slot_of_read int32[n])."""
+    qo = np.ascontiguousarray(q_off, np.int64)
+    jl = np.ascontiguousarray(job_len, np.int32)
+    n = len(qo) - 1
+    slot = np.zeros(max(n, 1), np.int32)
+    info = _lib.SfaPlanInfo()
+    _check(_lib.load().sfa_plan_batch(qo.ctypes.data_as(_lib.i64p), n, jl.ctypes.data_as(_lib.i32p), len(jl),
+                                      int(ckpt_interval), int(ckpt_budget_bytes), slot.ctypes.data_as(_lib.i32p),
+                                      C.byref(info)), "sfa_plan_batch")
+    return {k: getattr(info, k) for k, _ in _lib.SfaPlanInfo._fields_}, slot[:n]
 
 
 EVENT_DTYPE = np.dtype([("start", "<u8"), ("length", "<f4"), ("mean", "<f4"), ("stdv", "<f4")], align=True)

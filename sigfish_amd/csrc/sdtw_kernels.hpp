@@ -10,16 +10,23 @@
 //   * strand flip, ref_st_offset, mapq                               src/sigfish.c:969-983
 //
 // Mapping to the machine (MI355X-first, not a translation of the CPU loops):
-//   * one read occupies ONE DPP ROW (16 lanes) of a wave64; four reads ride in a wave.  Lane g of a row owns
-//     R consecutive query rows (R = 4/8/16/32 -> queries up to 64/128/256/512 events), kept in VGPRs together
-//     with their running cost and start column.  No LDS, no barriers, no cost matrix.
+//   * one read occupies ONE DPP ROW (16 lanes) of a wave64; four reads ("a quad", equal query length) ride in
+//     a wave.  Lane g of a row owns R consecutive query rows (R = 4/8/16/32 -> queries up to 64/128/256/512
+//     events), kept in VGPRs together with their running cost.  No LDS, no barriers, no cost matrix.
 //   * the lanes of a row walk an anti-diagonal: at step t lane g is at reference column t-g, so the only
-//     cross-lane traffic per step is ONE `v_mov_b32_dpp row_shr:1` of the bottom cost (and one of its start
-//     column): the neighbour's value from the previous step is this lane's "up", the one before its "diagonal".
+//     cross-lane traffic per step is ONE `v_mov_b32_dpp row_shr:1` of the bottom cost: the neighbour's value
+//     from the previous step is this lane's "up", the one before its "diagonal".
 //   * +inf initial state makes not-yet-started columns (t-g < 0) and past-the-end columns harmless, so the inner
 //     loop carries no per-lane predication; reference arrays are padded in HBM so the per-lane 16-byte loads of
-//     four upcoming reference levels never leave the allocation.
-//   * per cell: v_sub, v_min3, v_add(|d|) (+ 2 v_cmp_eq, 2 v_cndmask when the start column is tracked).
+//     four upcoming reference levels never leave the allocation (they hit L1/L2: every wave streams the same
+//     few hundred KB).
+//   * TWO PASSES.  Pass 1 (sdtw_fill_kernel, >95 % of the time) evaluates costs only -- v_sub, v_min3,
+//     v_add(|d|) per cell -- finds every window minimum and the per-read top-2, and drops a checkpoint of the
+//     (R+1)-register anti-diagonal state every T steps.  Pass 2 (sdtw_trace_kernel) re-runs, for each read's
+//     WINNING candidate only, the few hundred steps between a checkpoint and the winning cell with start-column
+//     tracking switched on (+2 v_cmp_eq, +2 v_cndmask per cell); if the path turns out to begin before the
+//     checkpoint (start sentinel -1 survives) it backs off to an earlier one, ultimately to step 0.  Costs are
+//     restored bit-exactly from the checkpoint, so the recovered start equals the full traceback's.
 //   * all arithmetic is IEEE fp32 with denormals, no FMA contraction: every cell is bit-identical to the
 //     reference's row-major evaluation because each cell is a pure function of its three neighbours.
 #pragma once
@@ -33,13 +40,23 @@ constexpr int kLanesPerRead = 16;  // one DPP row
 constexpr int kReadsPerWave = 4;
 constexpr int kRefPad = 64;        // floats of padding on both sides of every (contig,strand) array in HBM
 constexpr int kStepsPerLoad = 4;   // reference levels fetched per 16-byte load
+constexpr int kMaxClasses = 4;     // query-length classes R = 32, 16, 8, 4
 
 struct __attribute__((packed, aligned(4))) float4u {
     float v[4];
 };
 
-// Arguments of one fill launch (one query-length class R).
-struct FillArgs {
+// A query-length class inside one launch.
+struct ClassDesc {
+    int32_t R;          // query rows per lane
+    int32_t quad_base;  // first quad
+    int32_t n_quads;
+    int32_t task_base;  // first task (fill: n_quads*n_chunks tasks, trace: n_quads tasks)
+    int64_t ck_base;    // float offset of this class's checkpoint region
+};
+
+// Everything the fill / trace kernels read.  Passed by value (kernarg segment).
+struct DpArgs {
     const float *queries;        // HBM: concatenated z-normalised event means, event order
     const int64_t *q_off;        // [n_reads+1]
     const int32_t *order;        // [n_quads_total*4] read index per (quad, slot) or -1
@@ -48,16 +65,24 @@ struct FillArgs {
     const int64_t *job_off;      // [n_jobs] offset of column 0 of job (contig,strand) in `ref`
     const int32_t *job_len;      // [n_jobs] rlen
     const int32_t *chunk_begin;  // [n_chunks+1] job ranges
-    float *p_best;               // partial results, index (quad*n_chunks+chunk)*4+slot
+    const int32_t *job_ck_off;   // [n_jobs+1] prefix sum of checkpoints per job (for the current interval)
+    float *ck;                   // checkpoint store
+    // partial results of the fill, index (quad*n_chunks+chunk)*4+slot
+    float *p_best;
     int32_t *p_end;
     int32_t *p_st;
     int32_t *p_job;
     float *p_second;
-    int32_t quad_base;  // first quad of this class
-    int32_t n_quads;    // quads in this class
+    // winners per read (written by finalize, read by trace)
+    int32_t *w_job;
+    int32_t *w_end;
+    ClassDesc cls[kMaxClasses];
+    int32_t n_cls;
     int32_t n_chunks;
-    int32_t n_tasks;    // n_quads * n_chunks
-    int32_t rev_query;  // 1: query rows are the events reversed (RNA without --invert)
+    int32_t n_tasks;
+    int32_t rev_query;     // 1: query rows are the events reversed (RNA without --invert)
+    int32_t ck_shift;      // checkpoint interval T = 1 << ck_shift steps; 0 = no checkpoints
+    int32_t trace_margin;  // pass 2 starts from the last checkpoint at least this many steps before the winner
 };
 
 __device__ __forceinline__ float dpp_row_shr1_zero(float v) {
@@ -73,31 +98,18 @@ __device__ __forceinline__ int dpp_row_shr1_zero(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
 }
 
-// Wave-uniform register pick: c[idx] for a scalar idx without turning into R v_cndmasks.
-template <int R, typename T>
-__device__ __forceinline__ T pick_uniform(const T (&a)[R], int idx) {
-    T out = a[R - 1];
-#define SFA_PICK(r)                               \
-    case r:                                       \
-        if (r < R - 1) {                          \
-            out = a[(r < R - 1) ? r : 0];         \
-            asm volatile("" : "+v"(out));         \
-        }                                         \
-        break;
-    switch (idx) {
-        SFA_PICK(0) SFA_PICK(1) SFA_PICK(2) SFA_PICK(3) SFA_PICK(4) SFA_PICK(5) SFA_PICK(6) SFA_PICK(7)
-        SFA_PICK(8) SFA_PICK(9) SFA_PICK(10) SFA_PICK(11) SFA_PICK(12) SFA_PICK(13) SFA_PICK(14) SFA_PICK(15)
-        SFA_PICK(16) SFA_PICK(17) SFA_PICK(18) SFA_PICK(19) SFA_PICK(20) SFA_PICK(21) SFA_PICK(22) SFA_PICK(23)
-        SFA_PICK(24) SFA_PICK(25) SFA_PICK(26) SFA_PICK(27) SFA_PICK(28) SFA_PICK(29) SFA_PICK(30)
-        default: break;
-    }
-#undef SFA_PICK
-    return out;
-}
+// Per-lane state lives in R-wide register tuples.  A wave-uniform (SGPR) index into such a tuple lowers to
+// s_set_gpr_idx_on / v_mov_b32 / s_set_gpr_idx_off on gfx950: one VALU op to read "the register that holds the
+// last query row", whatever the query length.
+template <typename T, int R>
+struct Vec {
+    typedef T type __attribute__((ext_vector_type(R)));
+};
 
 // Running top-2 of the reference's candidate list for one read (kept in the registers of the lane that owns
 // the last query row).  Insertion rule of update_aln (src/sigfish.c:577-583): a candidate goes in front of
 // everything that is not strictly better, so on equal scores the LATER candidate ranks higher.
+template <bool TRACK>
 struct Top2 {
     float best, second;
     int32_t end, st, job;
@@ -114,30 +126,81 @@ struct Top2 {
         second = top ? best : (sec ? sc : second);
         best = top ? sc : best;
         end = top ? pos : end;
-        st = top ? start : st;
+        if (TRACK) st = top ? start : st;
         job = top ? j : job;
     }
 };
 
 // XCD-aware block remap (8 XCDs, blocks dealt round-robin): each XCD gets a contiguous range of logical
-// blocks, hence (tasks being chunk-major) mostly one reference chunk per XCD L2.  Speed only.
+// blocks, hence (tasks being chunk-major inside a class) mostly one reference chunk per XCD L2.  Speed only.
 __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
     const int x = b & 7, i = b >> 3;
     const int q = nblk >> 3, rem = nblk & 7;
     return x * q + (x < rem ? x : rem) + i;
 }
 
+// One anti-diagonal step for the R rows of this lane at reference level yv.
+//   c[r]   cost of row r at this lane's previous column ("left"); updated in place
+//   s[r]   start column carried with it (TRACK only)
+//   dprev  the "up" input of the previous step, i.e. this step's diagonal input for row 0
+//   t      step index (wave-uniform int in the fill, per-lane in the trace); lane 0's column is t
+template <int R, bool TRACK, bool STD, typename TT>
+__device__ __forceinline__ void dp_step(typename Vec<float, R>::type &c, typename Vec<int, R>::type &s, float &dprev, int &sdprev,
+                                        const float (&x)[R], const float yv, const TT t, const bool lane0) {
+    // inputs from the lane above (query row g*R-1); lane 0 owns query row 0 and receives the boundary instead
+    float up;
+    if (!STD) {
+        up = dpp_row_shr1_zero(c[R - 1]);  // subsequence(): C[0][j] = d + 0  (free start)
+    } else {
+        up = dpp_row_shr1_old((t == 0) ? 0.0f : INFINITY, c[R - 1]);  // std_dtw(): C[0][0]=d, C[0][j]=d+C[0][j-1]
+    }
+    int sup = 0;
+    if (TRACK) sup = dpp_row_shr1_zero(s[R - 1]);
+    float diag = dprev;
+    int sdiag = sdprev;
+    dprev = up;
+    sdprev = sup;
+    if (STD) dprev = (t == 0) ? INFINITY : dprev;  // there is no column -1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float left = c[r];
+        const int sleft = s[r];
+        const float m = fminf(fminf(up, diag), left);  // v_min3_f32; no NaNs on this path
+        const float cn = fabsf(x[r] - yv) + m;
+        int sn = 0;
+        if (TRACK) {
+            // traceback order of path(): diagonal first, then left, then up (src/cdtw.c:134-146)
+            sn = (diag == m) ? sdiag : ((left == m) ? sleft : sup);
+            if (r == 0) sn = lane0 ? static_cast<int>(t) : sn;  // query row 0: the path starts in this column
+        }
+        diag = left;
+        sdiag = sleft;
+        up = cn;
+        sup = sn;
+        c[r] = cn;
+        s[r] = sn;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, int read, int qlen, int g) {
+    const float *q = a.queries + a.q_off[read >= 0 ? read : 0];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = g * R + r;
+        const int src = a.rev_query ? (qlen - 1 - i) : i;
+        x[r] = (read >= 0 && i < qlen) ? q[src] : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// Fill kernel.  R rows per lane; TRACK: carry the alignment start column; STD: std_dtw instead of subsequence.
-// grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, 1 task each).
+// Pass 1 (and, with TRACK, the single-pass variant): fill.  One wave-task = (quad, chunk of jobs).
 // ---------------------------------------------------------------------------------------------------------
 template <int R, bool TRACK, bool STD>
-__global__ void __launch_bounds__(256) sdtw_fill_kernel(const FillArgs a) {
-    const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
-    if (task >= a.n_tasks) return;  // wave-uniform
-    const int chunk = task / a.n_quads;
-    const int quad = a.quad_base + (task - chunk * a.n_quads);
+__device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local) {
+    const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
+    const int quad_local = task_local - chunk * cd.n_quads;
+    const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
     const int g = lane & (kLanesPerRead - 1);
     const int slot = lane >> 4;
@@ -149,88 +212,62 @@ __global__ void __launch_bounds__(256) sdtw_fill_kernel(const FillArgs a) {
     const int rq = (qlen - 1) - lq * R;
 
     float x[R];
-    {
-        const float *q = a.queries + a.q_off[read >= 0 ? read : 0];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = g * R + r;
-            const int src = a.rev_query ? (qlen - 1 - i) : i;
-            x[r] = (read >= 0 && i < qlen) ? q[src] : 0.0f;
-        }
-    }
+    load_query_rows<R>(x, a, read, qlen, g);
 
-    Top2 top;
+    Top2<TRACK> top;
     top.init();
+
+    const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
+    const int64_t ck_total = a.ck_shift ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
 
     const int jb = a.chunk_begin[chunk], je = a.chunk_begin[chunk + 1];
     for (int job = jb; job < je; ++job) {
         const int rlen = a.job_len[job];
         const float *yp = a.ref + a.job_off[job] - g;  // this lane's column at step t is t-g
 
-        float c[R];
-        int s[R];
+        typename Vec<float, R>::type c;
+        typename Vec<int, R>::type s;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             c[r] = INFINITY;
             s[r] = 0;
         }
-        float dprev = INFINITY;  // "up" input of the previous step = diagonal input of this one
+        float dprev = INFINITY;
         int sdprev = 0;
         float wmin = INFINITY;  // running minimum of the current last-row window
         int wpos = -1, wst = -1;
         int wleft = qlen;
+        float *ckp = nullptr;
+        if (!TRACK && T)
+            ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * ((R + 1) * 64) + lane;
 
         const int nsteps = rlen + lq;  // lane lq sees column rlen-1 at step rlen-1+lq
         float4u ycur = *reinterpret_cast<const float4u *>(yp);
         for (int t0 = 0; t0 < nsteps; t0 += kStepsPerLoad) {
             const float4u ynext = *reinterpret_cast<const float4u *>(yp + t0 + kStepsPerLoad);
+            if (!TRACK && T) {
+                // checkpoint k = t0/T of the state BEFORE step t0, for 1 <= k <= (rlen-1)/T
+                if (t0 != 0 && (t0 & (T - 1)) == 0 && t0 < rlen) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ckp[r * 64] = c[r];
+                    ckp[R * 64] = dprev;
+                    ckp += (R + 1) * 64;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u) {
                 const int t = t0 + u;
-                const float yv = ycur.v[u];
-                // inputs from the lane above (row g*R-1): lane 0 owns query row 0 and gets the boundary instead
-                float up;
-                if (!STD) {
-                    up = dpp_row_shr1_zero(c[R - 1]);  // row 0 of subsequence(): C[0][j] = d + 0
-                } else {
-                    up = dpp_row_shr1_old((t == 0) ? 0.0f : INFINITY, c[R - 1]);  // C[0][0]=d, C[0][j]=d+C[0][j-1]
-                }
-                int sup = 0;
-                if (TRACK) sup = dpp_row_shr1_zero(s[R - 1]);
-                float diag = dprev;
-                int sdiag = sdprev;
-                dprev = up;
-                sdprev = sup;
-                if (STD && t == 0) dprev = INFINITY;  // there is no column -1
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float left = c[r];
-                    const int sleft = s[r];
-                    const float m = fminf(fminf(up, diag), left);  // v_min3_f32; no NaNs on this path
-                    const float cn = fabsf(x[r] - yv) + m;
-                    int sn = 0;
-                    if (TRACK) {
-                        // traceback order of path(): diagonal first, then left, then up (src/cdtw.c:134-146)
-                        sn = (diag == m) ? sdiag : ((left == m) ? sleft : sup);
-                        if (r == 0) sn = lane0 ? t : sn;  // query row 0: the path starts in this column
-                    }
-                    diag = left;
-                    sdiag = sleft;
-                    up = cn;
-                    sup = sn;
-                    c[r] = cn;
-                    s[r] = sn;
-                }
+                dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0);
                 // last query row: windowed first-strict-minimum scan (wave-uniform control flow)
                 const int jq = t - lq;
                 if (jq >= 0 && jq < rlen) {
-                    const float cl = pick_uniform<R>(c, rq);
-                    const int sl = TRACK ? pick_uniform<R>(s, rq) : 0;
+                    const float cl = c[rq];
+                    const int sl = TRACK ? s[rq] : 0;
                     if (!STD) {
                         const bool lt = cl < wmin;
                         wmin = lt ? cl : wmin;
                         wpos = lt ? jq : wpos;
-                        wst = lt ? sl : wst;
+                        if (TRACK) wst = lt ? sl : wst;
                         if (--wleft == 0 || jq == rlen - 1) {
                             top.offer(wmin, wpos, wst, job);
                             wmin = INFINITY;
@@ -252,9 +289,138 @@ __global__ void __launch_bounds__(256) sdtw_fill_kernel(const FillArgs a) {
         a.p_best[o] = top.best;
         a.p_second[o] = top.second;
         a.p_end[o] = top.end;
-        a.p_st[o] = top.st;
         a.p_job[o] = top.job;
+        if (TRACK) a.p_st[o] = top.st;
     }
+}
+
+// grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR bounds the classes compiled in,
+// so a batch without long queries does not pay the long variant's register budget.
+template <int MAXR, bool TRACK, bool STD>
+__global__ void __launch_bounds__(256) sdtw_fill_kernel(const DpArgs a) {
+    const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
+    if (task >= a.n_tasks) return;  // wave-uniform
+    int ci = 0;
+    while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
+    const ClassDesc cd = a.cls[ci];
+    const int tl = task - cd.task_base;
+    switch (cd.R) {
+        case 32:
+            if constexpr (MAXR >= 32) fill_body<32, TRACK, STD>(a, cd, tl);
+            break;
+        case 16:
+            if constexpr (MAXR >= 16) fill_body<16, TRACK, STD>(a, cd, tl);
+            break;
+        case 8:
+            if constexpr (MAXR >= 8) fill_body<8, TRACK, STD>(a, cd, tl);
+            break;
+        default:
+            fill_body<4, TRACK, STD>(a, cd, tl);
+            break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pass 2: start-column recovery for each read's winning candidate.  One wave = one quad; each 16-lane row
+// follows its own (job, end column, checkpoint), so the step index is per lane.
+// ---------------------------------------------------------------------------------------------------------
+struct ResultRow;  // below
+
+template <int R, bool STD>
+__device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st) {
+    const int quad = cd.quad_base + quad_local;
+    const int lane = threadIdx.x & 63;
+    const int g = lane & (kLanesPerRead - 1);
+    const int slot = lane >> 4;
+    const bool lane0 = (g == 0);
+
+    const int qlen = a.quad_qlen[quad];
+    const int read = a.order[quad * 4 + slot];
+    const int lq = (qlen - 1) / R;
+    const int rq = (qlen - 1) - lq * R;
+
+    float x[R];
+    load_query_rows<R>(x, a, read, qlen, g);
+
+    int job = (read >= 0) ? a.w_job[read] : -1;
+    const int end = (read >= 0) ? a.w_end[read] : 0;
+    bool done = !(read >= 0 && job >= 0 && end >= 0);
+    job = done ? 0 : job;
+    const int rlen = a.job_len[job];
+    const float *ybase = a.ref + a.job_off[job] - g;
+    const int t_end = end + lq;  // step at which lane lq evaluates the winning cell
+
+    const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
+    const int64_t ck_total = a.ck_shift ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
+    const int nck = T ? (rlen - 1) >> a.ck_shift : 0;  // checkpoints stored for this job
+    int k = 0;
+    if (T) {
+        const int from = t_end - a.trace_margin;
+        k = from > 0 ? (from >> a.ck_shift) : 0;
+        k = k < nck ? k : nck;
+    }
+    int back = 1;
+    int result = -1;
+
+    for (int attempt = 0; attempt < 40; ++attempt) {  // bounded: k reaches 0 after <= 32 halvings
+        const int tb = k << a.ck_shift;               // first step to execute
+        typename Vec<float, R>::type c;
+        typename Vec<int, R>::type s;
+        float dprev;
+        int sdprev;
+        if (k > 0) {  // restore the exact anti-diagonal state; provenance of these cells is unknown (-1)
+            const float *ckp = a.ck + cd.ck_base +
+                               (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job] + (k - 1)) * ((R + 1) * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c[r] = ckp[r * 64];
+                s[r] = -1;
+            }
+            dprev = ckp[R * 64];
+            sdprev = -1;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c[r] = INFINITY;
+                s[r] = 0;
+            }
+            dprev = INFINITY;
+            sdprev = 0;
+        }
+        const int len = done ? 0 : (t_end - tb + 1);
+        int maxlen = __builtin_amdgcn_readlane(len, 0);
+        maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
+        maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
+        maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
+        if (maxlen <= 0) break;
+
+        int cap = -2;
+        const int tlim = rlen + 16;  // keep the loads of rows that are already done inside the padded array
+        for (int tau0 = 0; tau0 < maxlen; tau0 += kStepsPerLoad) {
+            const int tbl = min(tb + tau0, tlim);
+            const float4u yv = *reinterpret_cast<const float4u *>(ybase + tbl);
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad; ++u) {
+                const int t = tb + tau0 + u;
+                dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t, lane0);
+                const int sl = s[rq];
+                cap = (t == t_end) ? sl : cap;
+            }
+        }
+        const int capq = __shfl(cap, (lane & 48) + lq);  // the lane that owns the last query row
+        if (!done) {
+            if (capq >= 0 || k == 0) {
+                result = capq;
+                done = true;
+            } else {  // the path starts before this checkpoint: back off (1, 2, 4, ... checkpoints)
+                k = max(0, k - back);
+                back <<= 1;
+            }
+        }
+        if (__all(done)) break;
+    }
+    if (g == lq && read >= 0) out_st[read] = result;
 }
 
 // One result row per read, POD mirror of sfa_result_t (include/sigfish_amd.h).
@@ -269,16 +435,44 @@ struct FinalizeArgs {
     const int32_t *slot_of_read;  // [n_reads] quad*4+slot, or -1 for skipped reads
     const float *p_best;
     const int32_t *p_end;
-    const int32_t *p_st;
+    const int32_t *p_st;  // single-pass variant only
     const int32_t *p_job;
     const float *p_second;
     const int32_t *job_contig;  // [n_jobs]
     const int8_t *job_strand;   // [n_jobs] '+' / '-'
     const int32_t *ref_len;     // [num_ref]
     const int32_t *ref_st_offset;
-    ResultRow *out;  // [n_reads]
+    int32_t *w_job;  // two-pass: winners for the trace kernel
+    int32_t *w_end;
+    const int32_t *t_st;  // two-pass, second finalize: start columns from the trace kernel
+    ResultRow *out;       // [n_reads]
     int32_t n_reads, n_chunks;
+    int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions
 };
+
+template <int MAXR, bool STD>
+__global__ void __launch_bounds__(256) sdtw_trace_kernel(const DpArgs a, int32_t *out_st) {
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (task >= a.n_tasks) return;
+    int ci = 0;
+    while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
+    const ClassDesc cd = a.cls[ci];
+    const int tl = task - cd.task_base;
+    switch (cd.R) {
+        case 32:
+            if constexpr (MAXR >= 32) trace_body<32, STD>(a, cd, tl, out_st);
+            break;
+        case 16:
+            if constexpr (MAXR >= 16) trace_body<16, STD>(a, cd, tl, out_st);
+            break;
+        case 8:
+            if constexpr (MAXR >= 8) trace_body<8, STD>(a, cd, tl, out_st);
+            break;
+        default:
+            trace_body<4, STD>(a, cd, tl, out_st);
+            break;
+    }
+}
 
 // src/sigfish.c:979-983: (int)round(500*(score2-score)/score) with x86 cvttsd2si saturation, cap 60, store u8
 __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
@@ -296,6 +490,20 @@ __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
 __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_reads) return;
+    const int sl = a.slot_of_read[i];
+    if (a.mode == 2) {  // positions from the traced start column
+        if (sl < 0) return;
+        ResultRow r = a.out[i];
+        if (r.rid < 0) return;
+        const int st = a.t_st[i];
+        const int end = a.w_end[i];
+        const int rl = a.ref_len[r.rid];
+        const int off = a.ref_st_offset[r.rid];
+        r.pos_st = ((r.strand == '+') ? st : rl - end) + off;  // src/sigfish.c:971-975
+        r.pos_end = ((r.strand == '+') ? end : rl - st) + off;
+        a.out[i] = r;
+        return;
+    }
     ResultRow r;
     r.rid = -1;
     r.pos_st = -1;
@@ -306,7 +514,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     r.mapq = 0;
     r.valid = 0;
     r.pad = 0;
-    const int sl = a.slot_of_read[i];
+    int wjob = -1, wend = -1;
     if (sl >= 0) {
         const int64_t quad = sl >> 2, slot = sl & 3;
         float best = INFINITY, second = INFINITY;
@@ -321,8 +529,8 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
             if (take) {
                 best = b;
                 end = a.p_end[o];
-                st = a.p_st[o];
                 job = a.p_job[o];
+                if (a.mode == 0) st = a.p_st[o];
             }
         }
         r.valid = 1;
@@ -331,14 +539,22 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
         if (job >= 0) {
             const int rid = a.job_contig[job];
             const int8_t d = a.job_strand[job];
-            const int rl = a.ref_len[rid];
-            const int off = a.ref_st_offset[rid];
             r.rid = rid;
             r.strand = d;
-            r.pos_st = ((d == '+') ? st : rl - end) + off;   // src/sigfish.c:971-975
-            r.pos_end = ((d == '+') ? end : rl - st) + off;
             r.mapq = mapq_from_scores(best, second);
+            if (a.mode == 0) {
+                const int rl = a.ref_len[rid];
+                const int off = a.ref_st_offset[rid];
+                r.pos_st = ((d == '+') ? st : rl - end) + off;
+                r.pos_end = ((d == '+') ? end : rl - st) + off;
+            }
+            wjob = job;
+            wend = end;
         }
+    }
+    if (a.mode == 1) {
+        a.w_job[i] = wjob;
+        a.w_end[i] = wend;
     }
     a.out[i] = r;
 }

@@ -3,19 +3,22 @@
 // Replaces the reference's accelerator hook align_db() (src/sigfish.c:1003-1015) and its init / teardown slots
 // (src/sigfish.c:200-204, 221-225).  Host work done here: pack the reference event arrays into one padded HBM
 // buffer, group reads into "quads" of equal query length (four reads share a wavefront), pick the
-// rows-per-lane class, launch, and hand back one row per read in input order.
+// rows-per-lane class, size the checkpoint interval, launch fill -> finalize -> trace -> finalize, and hand back
+// one row per read in input order.
 // There is NO CPU fallback: every failure is reported through the return code + sfa_last_error().
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/sigfish_amd.h"
 #include "sdtw_kernels.hpp"
+#include "sfa_plan.hpp"
 
 namespace {
 
@@ -48,7 +51,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
+        size_t want = bytes + bytes / 8 + 256;
         if (hipMalloc(&p, want) != hipSuccess) {
             p = nullptr;
             return fail(SFA_ENOMEM, "hipMalloc(%zu bytes) failed", want);
@@ -75,7 +78,7 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
+        size_t want = bytes + bytes / 8 + 256;
         if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
             p = nullptr;
             return fail(SFA_ENOMEM, "hipHostMalloc(%zu bytes) failed", want);
@@ -94,38 +97,21 @@ struct PinBuf {
     }
 };
 
-int rows_per_lane_for(int qlen) {
-    if (qlen <= 64) return 4;
-    if (qlen <= 128) return 8;
-    if (qlen <= 256) return 16;
-    if (qlen <= 512) return 32;
-    return 0;
-}
-
-// Split the job list into n_chunks contiguous, non-empty ranges of roughly equal reference columns.
-void split_jobs(const std::vector<int32_t> &job_len, int64_t total_cols, int32_t n_chunks, int32_t *chunk_begin) {
-    const int32_t n_jobs = static_cast<int32_t>(job_len.size());
-    int64_t acc = 0;
-    int32_t j = 0;
-    chunk_begin[0] = 0;
-    for (int32_t ch = 1; ch < n_chunks; ++ch) {
-        const int64_t want = total_cols * ch / n_chunks;
-        // take at least one job, then keep taking while below the target and enough jobs remain for the rest
-        acc += job_len[j++];
-        while (j < n_jobs - (n_chunks - ch) && acc + job_len[j] / 2 < want) acc += job_len[j++];
-        chunk_begin[ch] = j;
-    }
-    chunk_begin[n_chunks] = n_jobs;
-}
-
 }  // namespace
 
 struct sfa_ctx {
     int device = 0;
     uint32_t flag = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fill start, fill end, finalize end, spare
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end
     int cu_count = 256;
+
+    // tunables (sfa_set_option)
+    int64_t opt_single_pass = 0;             // 1: one fill with start tracking everywhere (first-round design)
+    int64_t opt_ckpt_interval = 0;           // force the checkpoint interval (power of two >= 4); 0 = auto
+    int64_t opt_ckpt_budget = 8ll << 30;     // bytes of HBM the checkpoints of one batch may take
+    int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = 2*qlen_max
+    int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
 
     // reference model (immutable after init)
     int32_t num_ref = 0, n_jobs = 0;
@@ -134,7 +120,7 @@ struct sfa_ctx {
     DevBuf d_ref, d_job_off, d_job_len, d_job_contig, d_job_strand, d_ref_len, d_ref_off;
 
     // per-batch scratch
-    DevBuf d_queries, d_qoff, d_order, d_quad_qlen, d_slot, d_chunk, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_out;
+    DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_tst, d_ck, d_out;
     PinBuf h_stage, h_out;
 
     sfa_profile_t prof{};
@@ -143,183 +129,198 @@ struct sfa_ctx {
 
 namespace {
 
-using sfa::FillArgs;
+using sfa::DpArgs;
 using sfa::FinalizeArgs;
 using sfa::ResultRow;
 
 static_assert(sizeof(ResultRow) == sizeof(sfa_result_t), "result row layout");
 
-template <int R>
-void launch_fill(bool std_dtw, const FillArgs &a, hipStream_t st) {
-    const int blocks = (a.n_tasks + 3) / 4;
-    if (std_dtw)
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<R, true, true>), dim3(blocks), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<R, true, false>), dim3(blocks), dim3(256), 0, st, a);
+template <bool TRACK>
+void launch_fill(int maxr, bool std_dtw, const DpArgs &a, hipStream_t st) {
+    const dim3 grid((a.n_tasks + 3) / 4), block(256);
+#define SFA_FILL(MR)                                                                                   \
+    if (std_dtw)                                                                                       \
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, true>), grid, block, 0, st, a);           \
+    else                                                                                               \
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, false>), grid, block, 0, st, a)
+    if (maxr >= 32) {
+        SFA_FILL(32);
+    } else if (maxr >= 16) {
+        SFA_FILL(16);
+    } else if (maxr >= 8) {
+        SFA_FILL(8);
+    } else {
+        SFA_FILL(4);
+    }
+#undef SFA_FILL
+}
+
+void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipStream_t st) {
+    const dim3 grid((a.n_tasks + 3) / 4), block(256);
+#define SFA_TRACE(MR)                                                                                  \
+    if (std_dtw)                                                                                       \
+        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<MR, true>), grid, block, 0, st, a, out_st);         \
+    else                                                                                               \
+        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<MR, false>), grid, block, 0, st, a, out_st)
+    if (maxr >= 32) {
+        SFA_TRACE(32);
+    } else if (maxr >= 16) {
+        SFA_TRACE(16);
+    } else if (maxr >= 8) {
+        SFA_TRACE(8);
+    } else {
+        SFA_TRACE(4);
+    }
+#undef SFA_TRACE
 }
 
 // Core of both align entry points: queries already in HBM, results left in HBM.
 int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out) {
     if (n == 0) return SFA_OK;
-    // ---- host: classify reads by query length, form quads of identical length ---------------------------
-    std::vector<int32_t> qlen(n);
-    int maxq = 0;
-    for (int32_t i = 0; i < n; ++i) {
-        const int64_t l = q_off[i + 1] - q_off[i];
-        if (l < 0) return fail(SFA_EINVAL, "q_off not monotone at read %d", i);
-        if (l > 512) return fail(SFA_ERANGE, "read %d has %lld events; this build supports up to 512", i, (long long)l);
-        qlen[i] = static_cast<int32_t>(l);
-        maxq = std::max(maxq, qlen[i]);
-    }
-    std::vector<int32_t> count(maxq + 2, 0);
-    for (int32_t i = 0; i < n; ++i) count[qlen[i]]++;
-    // classes in launch order: R = 32, 16, 8, 4 (long first); within a class by descending length
-    struct Cls {
-        int R, quad_base, n_quads;
-    };
-    std::vector<Cls> classes;
-    std::vector<int32_t> quad_start(maxq + 2, -1);  // first quad of each length
-    int32_t n_quads = 0;
-    for (int R : {32, 16, 8, 4}) {
-        Cls cl{R, n_quads, 0};
-        for (int l = maxq; l >= 1; --l) {
-            if (count[l] == 0 || rows_per_lane_for(l) != R) continue;
-            quad_start[l] = n_quads;
-            n_quads += (count[l] + 3) / 4;
-        }
-        cl.n_quads = n_quads - cl.quad_base;
-        if (cl.n_quads > 0) classes.push_back(cl);
-    }
-    const int32_t n_valid = n - count[0];
+    // ---- host: plan the batch (quads, classes, chunks, checkpoint interval) -------------------------------
+    sfa::PlanParams pp;
+    pp.n_sims = static_cast<int64_t>(c->cu_count) * 4;
+    pp.waves_per_simd = c->opt_waves_per_simd;
+    pp.single_pass = c->opt_single_pass != 0;
+    pp.ckpt_interval = c->opt_ckpt_interval;
+    pp.ckpt_budget_bytes = c->opt_ckpt_budget;
+    pp.trace_margin = c->opt_trace_margin;
+    sfa::BatchPlan plan;
+    std::string perr;
+    if (int rc = sfa::plan_batch(q_off, n, c->h_job_len, c->total_cols, pp, &plan, &perr)) return fail(rc, "%s", perr.c_str());
 
-    // chunking of the (contig,strand) job list: enough wave-tasks to fill the chip, otherwise one pass per read
-    int32_t n_chunks = 1;
-    if (n_quads > 0) {
-        const int64_t target = static_cast<int64_t>(c->cu_count) * 4 * 6;  // ~6 waves per SIMD
-        n_chunks = static_cast<int32_t>(std::min<int64_t>(c->n_jobs, std::max<int64_t>(1, target / n_quads)));
-    }
-    std::vector<int32_t> chunk_begin(n_chunks + 1);
-    split_jobs(c->h_job_len, c->total_cols, n_chunks, chunk_begin.data());
-
-    // staging layout (pinned): q_off[n+1] | order[n_quads*4] | quad_qlen[n_quads] | slot[n] | chunk_begin
-    const size_t sz_qoff = sizeof(int64_t) * (n + 1);
-    const size_t sz_order = sizeof(int32_t) * 4 * std::max(n_quads, 1);
-    const size_t sz_qq = sizeof(int32_t) * std::max(n_quads, 1);
-    const size_t sz_slot = sizeof(int32_t) * n;
-    const size_t sz_chunk = sizeof(int32_t) * (n_chunks + 1);
-    if (int rc = c->h_stage.reserve(sz_qoff + sz_order + sz_qq + sz_slot + sz_chunk)) return rc;
+    const int32_t n_quads = plan.n_quads, n_chunks = plan.n_chunks, n_jobs = c->n_jobs;
+    // staging layout: q_off[n+1] | order[4*n_quads] | quad_qlen[n_quads] | slot[n] | chunk_begin[n_chunks+1] | job_ck_off[n_jobs+1]
+    const size_t o_qoff = 0;
+    const size_t o_order = o_qoff + sizeof(int64_t) * (n + 1);
+    const size_t o_qq = o_order + sizeof(int32_t) * 4 * std::max(n_quads, 1);
+    const size_t o_slot = o_qq + sizeof(int32_t) * std::max(n_quads, 1);
+    const size_t o_chunk = o_slot + sizeof(int32_t) * n;
+    const size_t o_ckoff = o_chunk + sizeof(int32_t) * (n_chunks + 1);
+    const size_t stage_bytes = o_ckoff + sizeof(int32_t) * (n_jobs + 1);
+    int rc;
+    if ((rc = c->h_stage.reserve(stage_bytes)) || (rc = c->d_stage.reserve(stage_bytes))) return rc;
     char *hs = c->h_stage.as<char>();
-    int64_t *h_qoff = reinterpret_cast<int64_t *>(hs);
-    int32_t *h_order = reinterpret_cast<int32_t *>(hs + sz_qoff);
-    int32_t *h_qq = reinterpret_cast<int32_t *>(hs + sz_qoff + sz_order);
-    int32_t *h_slot = reinterpret_cast<int32_t *>(hs + sz_qoff + sz_order + sz_qq);
-    int32_t *h_chunk = reinterpret_cast<int32_t *>(hs + sz_qoff + sz_order + sz_qq + sz_slot);
-    memcpy(h_qoff, q_off, sz_qoff);
-    std::fill(h_order, h_order + 4 * std::max(n_quads, 1), -1);
-    std::vector<int32_t> fill_pos(maxq + 2, 0);
-    for (int32_t i = 0; i < n; ++i) {
-        const int l = qlen[i];
-        if (l == 0) {
-            h_slot[i] = -1;
-            continue;
-        }
-        const int32_t k = fill_pos[l]++;
-        const int32_t sl = (quad_start[l] + (k >> 2)) * 4 + (k & 3);
-        h_order[sl] = i;
-        h_slot[i] = sl;
-    }
-    for (int l = 1; l <= maxq; ++l)
-        if (count[l])
-            for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + 3) / 4; ++qd) h_qq[qd] = l;
-    memcpy(h_chunk, chunk_begin.data(), sz_chunk);
+    memcpy(hs + o_qoff, q_off, sizeof(int64_t) * (n + 1));
+    memcpy(hs + o_order, plan.order.data(), sizeof(int32_t) * plan.order.size());
+    memcpy(hs + o_qq, plan.quad_qlen.data(), sizeof(int32_t) * plan.quad_qlen.size());
+    memcpy(hs + o_slot, plan.slot_of_read.data(), sizeof(int32_t) * n);
+    memcpy(hs + o_chunk, plan.chunk_begin.data(), sizeof(int32_t) * (n_chunks + 1));
+    memcpy(hs + o_ckoff, plan.job_ck_off.data(), sizeof(int32_t) * (n_jobs + 1));
 
     const size_t n_part = static_cast<size_t>(std::max(n_quads, 1)) * n_chunks * 4;
-    int rc;
-    if ((rc = c->d_qoff.reserve(sz_qoff)) || (rc = c->d_order.reserve(sz_order)) || (rc = c->d_quad_qlen.reserve(sz_qq)) ||
-        (rc = c->d_slot.reserve(sz_slot)) || (rc = c->d_chunk.reserve(sz_chunk)) || (rc = c->d_pbest.reserve(4 * n_part)) ||
-        (rc = c->d_pend.reserve(4 * n_part)) || (rc = c->d_pst.reserve(4 * n_part)) || (rc = c->d_pjob.reserve(4 * n_part)) ||
-        (rc = c->d_psecond.reserve(4 * n_part)))
+    if ((rc = c->d_pbest.reserve(4 * n_part)) || (rc = c->d_pend.reserve(4 * n_part)) || (rc = c->d_pjob.reserve(4 * n_part)) ||
+        (rc = c->d_psecond.reserve(4 * n_part)) || (rc = c->d_wjob.reserve(4 * (size_t)n)) || (rc = c->d_wend.reserve(4 * (size_t)n)) ||
+        (rc = c->d_tst.reserve(4 * (size_t)n)))
         return rc;
+    if (plan.single_pass && (rc = c->d_pst.reserve(4 * n_part))) return rc;
+    if (!plan.single_pass && plan.ck_floats > 0 && (rc = c->d_ck.reserve(sizeof(float) * plan.ck_floats))) return rc;
 
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_qoff.p, h_qoff, sz_qoff, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->d_order.p, h_order, sz_order, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->d_quad_qlen.p, h_qq, sz_qq, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->d_slot.p, h_slot, sz_slot, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->d_chunk.p, h_chunk, sz_chunk, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->d_stage.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
+    char *ds = c->d_stage.as<char>();
 
-    // ---- device: fill (one launch per length class) + finalize ------------------------------------------
     const bool std_dtw = (c->flag & SFA_DTW) != 0;
-    FillArgs fa{};
-    fa.queries = d_queries;
-    fa.q_off = c->d_qoff.as<int64_t>();
-    fa.order = c->d_order.as<int32_t>();
-    fa.quad_qlen = c->d_quad_qlen.as<int32_t>();
-    fa.ref = c->d_ref.as<float>();
-    fa.job_off = c->d_job_off.as<int64_t>();
-    fa.job_len = c->d_job_len.as<int32_t>();
-    fa.chunk_begin = c->d_chunk.as<int32_t>();
-    fa.p_best = c->d_pbest.as<float>();
-    fa.p_end = c->d_pend.as<int32_t>();
-    fa.p_st = c->d_pst.as<int32_t>();
-    fa.p_job = c->d_pjob.as<int32_t>();
-    fa.p_second = c->d_psecond.as<float>();
-    fa.n_chunks = n_chunks;
-    fa.rev_query = ((c->flag & SFA_RNA) && !(c->flag & SFA_INV)) ? 1 : 0;
-
-    HIP_TRY(hipEventRecord(c->ev[0], st));
-    int64_t launches = 0;
-    for (const Cls &cl : classes) {
-        fa.quad_base = cl.quad_base;
-        fa.n_quads = cl.n_quads;
-        fa.n_tasks = cl.n_quads * n_chunks;
-        switch (cl.R) {
-            case 4: launch_fill<4>(std_dtw, fa, st); break;
-            case 8: launch_fill<8>(std_dtw, fa, st); break;
-            case 16: launch_fill<16>(std_dtw, fa, st); break;
-            default: launch_fill<32>(std_dtw, fa, st); break;
-        }
-        HIP_TRY(hipGetLastError());
-        ++launches;
+    DpArgs da{};
+    da.queries = d_queries;
+    da.q_off = reinterpret_cast<const int64_t *>(ds + o_qoff);
+    da.order = reinterpret_cast<const int32_t *>(ds + o_order);
+    da.quad_qlen = reinterpret_cast<const int32_t *>(ds + o_qq);
+    da.ref = c->d_ref.as<float>();
+    da.job_off = c->d_job_off.as<int64_t>();
+    da.job_len = c->d_job_len.as<int32_t>();
+    da.chunk_begin = reinterpret_cast<const int32_t *>(ds + o_chunk);
+    da.job_ck_off = reinterpret_cast<const int32_t *>(ds + o_ckoff);
+    da.ck = c->d_ck.as<float>();
+    da.p_best = c->d_pbest.as<float>();
+    da.p_end = c->d_pend.as<int32_t>();
+    da.p_st = c->d_pst.as<int32_t>();
+    da.p_job = c->d_pjob.as<int32_t>();
+    da.p_second = c->d_psecond.as<float>();
+    da.w_job = c->d_wjob.as<int32_t>();
+    da.w_end = c->d_wend.as<int32_t>();
+    da.n_cls = static_cast<int32_t>(plan.classes.size());
+    for (int i = 0; i < da.n_cls; ++i) {
+        da.cls[i].R = plan.classes[i].R;
+        da.cls[i].quad_base = plan.classes[i].quad_base;
+        da.cls[i].n_quads = plan.classes[i].n_quads;
+        da.cls[i].task_base = plan.classes[i].quad_base * n_chunks;  // classes are contiguous in quad order
+        da.cls[i].ck_base = plan.classes[i].ck_base;
     }
-    HIP_TRY(hipEventRecord(c->ev[1], st));
+    da.n_chunks = n_chunks;
+    da.n_tasks = n_quads * n_chunks;
+    da.rev_query = ((c->flag & SFA_RNA) && !(c->flag & SFA_INV)) ? 1 : 0;
+    da.ck_shift = plan.single_pass ? 0 : plan.ck_shift;
+    da.trace_margin = plan.trace_margin;
 
     FinalizeArgs fz{};
-    fz.slot_of_read = c->d_slot.as<int32_t>();
-    fz.p_best = fa.p_best;
-    fz.p_end = fa.p_end;
-    fz.p_st = fa.p_st;
-    fz.p_job = fa.p_job;
-    fz.p_second = fa.p_second;
+    fz.slot_of_read = reinterpret_cast<const int32_t *>(ds + o_slot);
+    fz.p_best = da.p_best;
+    fz.p_end = da.p_end;
+    fz.p_st = da.p_st;
+    fz.p_job = da.p_job;
+    fz.p_second = da.p_second;
     fz.job_contig = c->d_job_contig.as<int32_t>();
     fz.job_strand = c->d_job_strand.as<int8_t>();
     fz.ref_len = c->d_ref_len.as<int32_t>();
     fz.ref_st_offset = c->d_ref_off.as<int32_t>();
+    fz.w_job = da.w_job;
+    fz.w_end = da.w_end;
+    fz.t_st = c->d_tst.as<int32_t>();
     fz.out = d_out;
     fz.n_reads = n;
     fz.n_chunks = n_chunks;
-    hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, fz);
+    const dim3 fgrid((n + 255) / 256), fblock(256);
+
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (n_quads > 0) {
+        if (plan.single_pass)
+            launch_fill<true>(plan.max_R, std_dtw, da, st);
+        else
+            launch_fill<false>(plan.max_R, std_dtw, da, st);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev[1], st));
+    fz.mode = plan.single_pass ? 0 : 1;
+    hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[2], st));
+    if (!plan.single_pass && n_quads > 0) {
+        DpArgs ta = da;
+        for (int i = 0; i < ta.n_cls; ++i) ta.cls[i].task_base = ta.cls[i].quad_base;  // one task per quad
+        ta.n_tasks = n_quads;
+        launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        fz.mode = 2;
+        hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+    }
+    HIP_TRY(hipEventRecord(c->ev[4], st));
 
-    int64_t qsum = 0;
-    for (int32_t i = 0; i < n; ++i) qsum += qlen[i];
-    c->prof.cells = qsum * c->total_cols;
-    c->prof.fill_launches = launches;
+    c->prof.cells = plan.query_events * c->total_cols;
+    c->prof.fill_launches = n_quads > 0 ? 1 : 0;
+    c->prof.ckpt_interval = plan.single_pass ? 0 : (plan.ck_shift ? (1 << plan.ck_shift) : 0);
+    c->prof.ckpt_bytes = plan.single_pass ? 0 : static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
+    c->prof.n_tasks = da.n_tasks;
+    c->prof.n_chunks = n_chunks;
     c->prof_pending = true;
-    (void)n_valid;
     return SFA_OK;
 }
 
 int resolve_profile(sfa_ctx *c) {
     if (!c->prof_pending) return SFA_OK;
-    HIP_TRY(hipEventSynchronize(c->ev[2]));
-    float a = 0, b = 0, t = 0;
+    HIP_TRY(hipEventSynchronize(c->ev[4]));
+    float a = 0, b = 0, d = 0, t = 0;
     HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[4]));
     c->prof.fill_ms = a;
-    c->prof.finalize_ms = b;
+    c->prof.trace_ms = d;
+    c->prof.finalize_ms = t - a - d;
     c->prof.total_ms = t;
     c->prof_pending = false;
     return SFA_OK;
@@ -395,7 +396,7 @@ int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {
         (rc = c->d_job_strand.reserve(c->n_jobs)) || (rc = c->d_ref_len.reserve(sizeof(int32_t) * ref->num_ref)) ||
         (rc = c->d_ref_off.reserve(sizeof(int32_t) * ref->num_ref)))
         return bail(rc);
-#define UP(dst, src, bytes)                                                                        \
+#define UP(dst, src, bytes) \
     if (hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(SFA_ENODEV, "upload of reference model failed"))
     UP(c->d_ref.p, packed.data(), sizeof(float) * total);
     UP(c->d_job_off.p, job_off.data(), sizeof(int64_t) * c->n_jobs);
@@ -414,8 +415,8 @@ void sfa_destroy(sfa_ctx_t *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_ref, &c->d_job_off, &c->d_job_len, &c->d_job_contig, &c->d_job_strand, &c->d_ref_len, &c->d_ref_off,
-                      &c->d_queries, &c->d_qoff, &c->d_order, &c->d_quad_qlen, &c->d_slot, &c->d_chunk, &c->d_pbest, &c->d_pend,
-                      &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_out})
+                      &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
+                      &c->d_wend, &c->d_tst, &c->d_ck, &c->d_out})
         b->release();
     c->h_stage.release();
     c->h_out.release();
@@ -425,9 +426,34 @@ void sfa_destroy(sfa_ctx_t *c) {
     delete c;
 }
 
+int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
+    if (!c || !key) return fail(SFA_EINVAL, "sfa_set_option: null argument");
+    const std::string k(key);
+    if (k == "single_pass") {
+        c->opt_single_pass = value != 0;
+    } else if (k == "ckpt_interval") {
+        if (value != 0 && (value < 4 || (value & (value - 1)))) return fail(SFA_EINVAL, "ckpt_interval must be 0 or a power of two >= 4");
+        c->opt_ckpt_interval = value;
+    } else if (k == "ckpt_budget_bytes") {
+        if (value < 0) return fail(SFA_EINVAL, "ckpt_budget_bytes must be >= 0");
+        c->opt_ckpt_budget = value;
+    } else if (k == "trace_margin") {
+        c->opt_trace_margin = value;
+    } else if (k == "waves_per_simd") {
+        if (value < 1 || value > 8) return fail(SFA_EINVAL, "waves_per_simd must be 1..8");
+        c->opt_waves_per_simd = value;
+    } else {
+        return fail(SFA_EINVAL, "unknown option '%s'", key);
+    }
+    return SFA_OK;
+}
+
 int sfa_align_batch_device(sfa_ctx_t *c, const float *d_queries, const int64_t *q_off, int32_t n, sfa_result_t *d_out, int sync) {
     if (!c || !q_off || n < 0 || (n > 0 && (!d_queries || !d_out))) return fail(SFA_EINVAL, "sfa_align_batch_device: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    // the pinned staging area is reused by every call: the previous batch must have left it
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = resolve_profile(c)) return rc;
     if (int rc = align_device(c, d_queries, q_off, n, reinterpret_cast<ResultRow *>(d_out))) return rc;
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -440,6 +466,7 @@ int sfa_align_batch(sfa_ctx_t *c, const float *queries, const int64_t *q_off, in
     if (!c || !q_off || n < 0 || (n > 0 && (!queries || !out))) return fail(SFA_EINVAL, "sfa_align_batch: bad argument");
     if (n == 0) return SFA_OK;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     const int64_t nq = q_off[n] - q_off[0];
     if (nq < 0) return fail(SFA_EINVAL, "q_off not monotone");
     int rc;

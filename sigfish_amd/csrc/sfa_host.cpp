@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/sigfish_amd.h"
+#include "sfa_plan.hpp"
 
 namespace {
 
@@ -98,6 +99,30 @@ int32_t sfa_gen_ref_record(const char *seq, int32_t len, const float *level_mean
     if (!rna) sfa_znormalise(rev, static_cast<uint64_t>(n));
     if (st_offset) *st_offset = off;
     return n;
+}
+
+int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len, int32_t n_jobs, int64_t ckpt_interval,
+                   int64_t ckpt_budget_bytes, int32_t *slot_of_read, sfa_plan_info_t *info) {
+    if (!q_off || n_reads < 0 || !job_len || n_jobs <= 0 || !info) return SFA_EINVAL;
+    std::vector<int32_t> jl(job_len, job_len + n_jobs);
+    int64_t total = 0;
+    for (int32_t v : jl) total += v;
+    sfa::PlanParams pp;
+    pp.ckpt_interval = ckpt_interval;
+    if (ckpt_budget_bytes > 0) pp.ckpt_budget_bytes = ckpt_budget_bytes;
+    sfa::BatchPlan plan;
+    std::string err;
+    if (int rc = sfa::plan_batch(q_off, n_reads, jl, total, pp, &plan, &err)) return rc;
+    if (slot_of_read) memcpy(slot_of_read, plan.slot_of_read.data(), sizeof(int32_t) * n_reads);
+    info->n_quads = plan.n_quads;
+    info->n_chunks = plan.n_chunks;
+    info->n_classes = static_cast<int32_t>(plan.classes.size());
+    info->max_rows_per_lane = plan.max_R;
+    info->ckpt_interval = plan.ck_shift ? (1 << plan.ck_shift) : 0;
+    info->trace_margin = plan.trace_margin;
+    info->ckpt_bytes = plan.ck_floats * 4;
+    info->n_tasks = static_cast<int64_t>(plan.n_quads) * plan.n_chunks;
+    return SFA_OK;
 }
 
 int sfa_paf_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname,

@@ -1,0 +1,170 @@
+// sfa_plan.hpp -- host-side batch planning for the sDTW kernels (pure C++, no HIP; unit-tested without a GPU).
+//
+// Replaces the reference's per-batch thread fan-out (work_db / pthread_db, src/thread.c:74-132: contiguous
+// read ranges per thread + work stealing) with a static plan for the GPU:
+//   * reads of EQUAL query length are grouped four at a time into "quads" (one wavefront each); lengths select
+//     a rows-per-lane class R (4/8/16/32) -- long classes first so that short work fills the tail;
+//   * the (contig,strand) job list is cut into contiguous chunks of similar size when there are too few quads
+//     to fill the chip; a wave-task is (quad, chunk);
+//   * the checkpoint interval T of pass 1 is the smallest power of two >= 1024 whose checkpoints fit the budget.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sfa {
+
+constexpr int kMaxQuery = 512;
+
+inline int rows_per_lane_for(int qlen) {
+    if (qlen <= 64) return 4;
+    if (qlen <= 128) return 8;
+    if (qlen <= 256) return 16;
+    if (qlen <= 512) return 32;
+    return 0;
+}
+
+struct PlanParams {
+    int64_t n_sims = 1024;          // SIMDs on the device (CUs * 4)
+    int64_t waves_per_simd = 6;     // occupancy to aim for when chunking
+    bool single_pass = false;
+    int64_t ckpt_interval = 0;      // 0 = auto
+    int64_t ckpt_budget_bytes = 8ll << 30;
+    int64_t trace_margin = -1;      // -1 = 2 * longest query
+};
+
+struct PlanClass {
+    int R = 0, quad_base = 0, n_quads = 0;
+    int64_t ck_base = 0;  // float offset
+};
+
+struct BatchPlan {
+    int32_t n_quads = 0, n_chunks = 1, max_R = 4, ck_shift = 0, trace_margin = 0;
+    bool single_pass = false;
+    int64_t ck_floats = 0, query_events = 0;
+    std::vector<int32_t> order;         // [4*max(n_quads,1)] read per (quad,slot) or -1
+    std::vector<int32_t> quad_qlen;     // [max(n_quads,1)]
+    std::vector<int32_t> slot_of_read;  // [n] quad*4+slot or -1 (skipped read)
+    std::vector<int32_t> chunk_begin;   // [n_chunks+1]
+    std::vector<int32_t> job_ck_off;    // [n_jobs+1]
+    std::vector<PlanClass> classes;
+};
+
+// Split the job list into n_chunks contiguous, non-empty ranges of roughly equal reference columns.
+inline void split_jobs(const std::vector<int32_t> &job_len, int64_t total_cols, int32_t n_chunks, int32_t *chunk_begin) {
+    const int32_t n_jobs = static_cast<int32_t>(job_len.size());
+    int64_t acc = 0;
+    int32_t j = 0;
+    chunk_begin[0] = 0;
+    for (int32_t ch = 1; ch < n_chunks; ++ch) {
+        const int64_t want = total_cols * ch / n_chunks;
+        acc += job_len[j++];  // at least one job per chunk
+        while (j < n_jobs - (n_chunks - ch) && acc + job_len[j] / 2 < want) acc += job_len[j++];
+        chunk_begin[ch] = j;
+    }
+    chunk_begin[n_chunks] = n_jobs;
+}
+
+inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t> &job_len, int64_t total_cols,
+                      const PlanParams &pp, BatchPlan *out, std::string *err) {
+    BatchPlan &p = *out;
+    p = BatchPlan();
+    p.single_pass = pp.single_pass;
+    const int32_t n_jobs = static_cast<int32_t>(job_len.size());
+    std::vector<int32_t> qlen(n);
+    int maxq = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t l = q_off[i + 1] - q_off[i];
+        if (l < 0) {
+            *err = "q_off is not monotone at read " + std::to_string(i);
+            return -1;  // SFA_EINVAL
+        }
+        if (l > kMaxQuery) {
+            *err = "read " + std::to_string(i) + " has " + std::to_string(l) + " events; the limit is " + std::to_string(kMaxQuery);
+            return -4;  // SFA_ERANGE
+        }
+        qlen[i] = static_cast<int32_t>(l);
+        maxq = std::max(maxq, qlen[i]);
+        p.query_events += l;
+    }
+    std::vector<int32_t> count(maxq + 2, 0);
+    for (int32_t i = 0; i < n; ++i) count[qlen[i]]++;
+    // classes in task order: R = 32, 16, 8, 4 (long first); inside a class by descending length
+    std::vector<int32_t> quad_start(maxq + 2, -1);
+    int32_t n_quads = 0;
+    for (int R : {32, 16, 8, 4}) {
+        PlanClass cl;
+        cl.R = R;
+        cl.quad_base = n_quads;
+        for (int l = maxq; l >= 1; --l) {
+            if (count[l] == 0 || rows_per_lane_for(l) != R) continue;
+            quad_start[l] = n_quads;
+            n_quads += (count[l] + 3) / 4;
+        }
+        cl.n_quads = n_quads - cl.quad_base;
+        if (cl.n_quads > 0) p.classes.push_back(cl);
+    }
+    p.n_quads = n_quads;
+    p.max_R = p.classes.empty() ? 4 : p.classes.front().R;
+    p.order.assign(4 * static_cast<size_t>(std::max(n_quads, 1)), -1);
+    p.quad_qlen.assign(std::max(n_quads, 1), 1);
+    p.slot_of_read.assign(n, -1);
+    std::vector<int32_t> fill_pos(maxq + 2, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        const int l = qlen[i];
+        if (l == 0) continue;
+        const int32_t k = fill_pos[l]++;
+        const int32_t sl = (quad_start[l] + (k >> 2)) * 4 + (k & 3);
+        p.order[sl] = i;
+        p.slot_of_read[i] = sl;
+    }
+    for (int l = 1; l <= maxq; ++l)
+        if (count[l])
+            for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + 3) / 4; ++qd) p.quad_qlen[qd] = l;
+
+    // chunk the job list only as far as needed to fill the machine
+    p.n_chunks = 1;
+    if (n_quads > 0 && n_jobs > 1) {
+        const int64_t target = pp.n_sims * pp.waves_per_simd;
+        p.n_chunks = static_cast<int32_t>(std::min<int64_t>(n_jobs, std::max<int64_t>(1, target / n_quads)));
+    }
+    p.chunk_begin.resize(p.n_chunks + 1);
+    split_jobs(job_len, total_cols, p.n_chunks, p.chunk_begin.data());
+
+    // checkpoint interval
+    p.job_ck_off.assign(n_jobs + 1, 0);
+    p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : 2 * maxq);
+    if (!pp.single_pass && n_quads > 0) {
+        int shift = 10;
+        if (pp.ckpt_interval > 0) {
+            shift = 0;
+            while ((1ll << shift) < pp.ckpt_interval) ++shift;
+        }
+        for (;; ++shift) {
+            int64_t per_quad = 0;
+            for (int32_t j = 0; j < n_jobs; ++j) per_quad += (job_len[j] - 1) >> shift;
+            int64_t floats = 0;
+            for (const PlanClass &cl : p.classes) floats += per_quad * cl.n_quads * (cl.R + 1) * 64;
+            if (pp.ckpt_interval > 0 || floats * 4 <= pp.ckpt_budget_bytes || per_quad == 0 || shift >= 30) {
+                p.ck_shift = shift;
+                p.ck_floats = floats;
+                break;
+            }
+        }
+        int64_t base = 0, per_quad = 0;
+        for (int32_t j = 0; j < n_jobs; ++j) {
+            p.job_ck_off[j] = static_cast<int32_t>(per_quad);
+            per_quad += (job_len[j] - 1) >> p.ck_shift;
+        }
+        p.job_ck_off[n_jobs] = static_cast<int32_t>(per_quad);
+        for (PlanClass &cl : p.classes) {
+            cl.ck_base = base;
+            base += per_quad * cl.n_quads * (cl.R + 1) * 64;
+        }
+    }
+    return 0;
+}
+
+}  // namespace sfa

@@ -86,3 +86,43 @@ def test_paf_rows_from_golden_rows(name):
                                int(c["ref_seq_lengths"][int(r["rid"])])))
         vi += 1
     assert "".join(lines) == c["out_text"]
+
+
+def test_plan_batch_layout():
+    """Host planning logic (the GPU-side replacement of thread.c's fan-out), checked without a GPU."""
+    from sigfish_amd.api import plan_batch
+    rng = np.random.default_rng(3)
+    lens = rng.choice([0, 1, 25, 64, 65, 128, 129, 250, 250, 250, 256, 257, 512], size=1000)
+    q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    info, slot = plan_batch(q_off, [29898, 29898])
+    assert (slot[lens == 0] == -1).all()
+    used = slot[lens > 0]
+    assert len(np.unique(used)) == len(used)            # one slot per read
+    quads = used >> 2
+    for qd in np.unique(quads):                          # a quad holds reads of ONE length
+        assert len(set(lens[lens > 0][quads == qd])) == 1
+    assert info["n_quads"] == len(np.unique(quads))
+    assert info["n_classes"] == 4 and info["max_rows_per_lane"] == 32
+    assert 1 <= info["n_chunks"] <= 2 and info["n_tasks"] == info["n_quads"] * info["n_chunks"]
+    assert info["ckpt_interval"] == 1024 and info["trace_margin"] == 1024
+    # long classes come first in task order
+    order = np.argsort(used)
+    l_sorted = lens[lens > 0][order]
+    rpl = np.select([l_sorted <= 64, l_sorted <= 128, l_sorted <= 256], [4, 8, 16], 32)
+    assert (np.diff(rpl) <= 0).all()
+    # a tight budget raises the interval instead of failing
+    info2, _ = plan_batch(q_off, [29898, 29898], ckpt_budget_bytes=1 << 20)
+    assert info2["ckpt_interval"] > 1024 and info2["ckpt_bytes"] <= 1 << 20
+    # few reads, many contigs: the contig list is chunked to fill the machine
+    info3, _ = plan_batch(np.array([0, 250, 500], np.int64), [375] * 160)
+    assert info3["n_quads"] == 1 and info3["n_chunks"] == 160
+    with pytest.raises(S.SfaError):
+        plan_batch(np.array([0, 600], np.int64), [100])
+
+
+def test_plan_batch_empty_and_single():
+    from sigfish_amd.api import plan_batch
+    info, slot = plan_batch(np.array([0, 0, 0], np.int64), [50])
+    assert info["n_quads"] == 0 and (slot == -1).all()
+    info, slot = plan_batch(np.array([0, 7], np.int64), [50])
+    assert info["n_quads"] == 1 and slot[0] == 0

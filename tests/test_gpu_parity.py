@@ -27,12 +27,24 @@ def assert_rows_equal(got, want):
     assert np.array_equal(got["score2"][v].view(np.uint32), want["score2"][v].view(np.uint32))
 
 
+# the two-pass default, the single-pass variant, and a configuration that forces dense checkpoints + back-off
+MODES = {"two_pass": {}, "single_pass": {"single_pass": 1}, "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0}}
+
+
+def _aligner(ref, flag, mode="two_pass"):
+    al = S.Aligner(ref, flag)
+    for k, v in MODES[mode].items():
+        al.set_option(k, v)
+    return al
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", case_names())
-def test_golden_cases(oracle, name):
+def test_golden_cases(oracle, name, mode):
     """Fixture inputs (real reads, reference-built event arrays) -> rows and PAF text of the compiled reference."""
     c = load_case(name)
     ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
-    with S.Aligner(ref, c["flag"]) as al:
+    with _aligner(ref, c["flag"], mode) as al:
         res = al.align_db(c["queries"], c["q_off"])
     for f in ("rid", "pos_st", "pos_end", "mapq", "strand"):
         assert np.array_equal(res[f], c[f]), (f, res[f], c[f])
@@ -74,9 +86,10 @@ def _small_ref(rng, lens, rna, quant=False):
                       fw, rv)
 
 
+@pytest.mark.parametrize("gpu_mode", list(MODES))
 @pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
-def test_ragged_and_ties(oracle, seed, mode):
+def test_ragged_and_ties(oracle, seed, mode, gpu_mode):
     """Edge cases the reference's own runs exercise: ragged query lengths (incl. 1..24 and >256), empty reads,
     contigs shorter than the query, exact ties from quantised levels, batches that do not fill a wavefront."""
     rng = np.random.default_rng(1000 + seed)
@@ -93,10 +106,37 @@ def test_ragged_and_ties(oracle, seed, mode):
         qlens[:] = 250
     q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
     q = (rng.integers(-6, 7, int(q_off[-1])) / 4).astype(np.float32) if quant else rng.normal(size=int(q_off[-1])).astype(np.float32)
-    with S.Aligner(ref, flag) as al:
+    with _aligner(ref, flag, gpu_mode) as al:
         got = al.align_db(q, q_off)
     want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=8)
     assert_rows_equal(got, want)
+
+
+@pytest.mark.parametrize("interval,margin", [(4, 0), (8, 3), (64, 0), (256, 100), (1024, -1)])
+def test_checkpoint_intervals(oracle, interval, margin):
+    """Pass 2 must recover the same start column from any checkpoint spacing, including the back-off path
+    (margin 0 starts right at the winner, so the path almost always begins before the first checkpoint tried)."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=37, seed=5)
+    with S.Aligner(ref, flag) as al:
+        al.set_option("ckpt_interval", interval)
+        al.set_option("trace_margin", margin)
+        got = al.align_db(q, q_off)
+        prof = al.profile()
+    assert prof["ckpt_interval"] == interval
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16)
+    assert_rows_equal(got, want)
+
+
+def test_checkpoint_budget_picks_larger_interval():
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=64, seed=6)
+    with S.Aligner(ref, flag) as al:
+        a = al.align_db(q, q_off)
+        pa = al.profile()
+        al.set_option("ckpt_budget_bytes", 64 * 1024)
+        b = al.align_db(q, q_off)
+        pb = al.profile()
+    assert pa["ckpt_interval"] == 1024 and pb["ckpt_interval"] > 1024 and pb["ckpt_bytes"] <= 64 * 1024
+    assert a.tobytes() == b.tobytes()
 
 
 def test_align_events_entry(oracle):
