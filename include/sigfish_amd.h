@@ -124,7 +124,7 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
                      const int64_t *qstart, const int64_t *qend, int32_t n_reads, sfa_result_t *out);
 
 /* Tuning knobs (all optional): "single_pass" (0/1: track start columns in one pass instead of fill + trace),
- * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = 2*qlen),
+ * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = qlen+16),
  * "waves_per_simd" (1..8, occupancy target used when splitting the contig list). */
 int sfa_set_option(sfa_ctx_t *ctx, const char *key, int64_t value);
 

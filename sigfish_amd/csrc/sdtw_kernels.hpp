@@ -106,6 +106,15 @@ struct Vec {
     typedef T type __attribute__((ext_vector_type(R)));
 };
 
+// The same pick as a select chain, for the handful of steps outside the steady-state loop.
+template <int R, typename T>
+__device__ __forceinline__ T pick_chain(const T (&a)[R], int idx) {
+    T out = a[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) out = (idx == r) ? a[r] : out;
+    return out;
+}
+
 // Running top-2 of the reference's candidate list for one read (kept in the registers of the lane that owns
 // the last query row).  Insertion rule of update_aln (src/sigfish.c:577-583): a candidate goes in front of
 // everything that is not strictly better, so on equal scores the LATER candidate ranks higher.
@@ -144,9 +153,9 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
 //   s[r]   start column carried with it (TRACK only)
 //   dprev  the "up" input of the previous step, i.e. this step's diagonal input for row 0
 //   t      step index (wave-uniform int in the fill, per-lane in the trace); lane 0's column is t
-template <int R, bool TRACK, bool STD, typename TT>
-__device__ __forceinline__ void dp_step(typename Vec<float, R>::type &c, typename Vec<int, R>::type &s, float &dprev, int &sdprev,
-                                        const float (&x)[R], const float yv, const TT t, const bool lane0) {
+template <int R, bool TRACK, bool STD, typename TT, typename CF, typename CI>
+__device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev, const float (&x)[R], const float yv, const TT t,
+                                        const bool lane0) {
     // inputs from the lane above (query row g*R-1); lane 0 owns query row 0 and receives the boundary instead
     float up;
     if (!STD) {
@@ -196,6 +205,13 @@ __device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, 
 // ---------------------------------------------------------------------------------------------------------
 // Pass 1 (and, with TRACK, the single-pass variant): fill.  One wave-task = (quad, chunk of jobs).
 // ---------------------------------------------------------------------------------------------------------
+// Time origin.  Lane lq (owner of the last query row) meets reference column 0 at step t = lq.  Steps are issued
+// in blocks of four (one 16-byte load of reference levels per block), so the sweep starts at
+// t_begin = lq - roundup4(lq) in (-4, 0]: the first roundup4(lq) steps are a prologue with no last-row work, and
+// from then on block b covers last-row columns 4b..4b+3 with no per-step range checks.  Columns < 0 read the
+// +inf padding in front of every reference array, which keeps those cells at +inf.
+__device__ __forceinline__ int sweep_begin(int lq) { return lq - ((lq + 3) & ~3); }
+
 template <int R, bool TRACK, bool STD>
 __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
@@ -206,10 +222,11 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     const int slot = lane >> 4;
     const bool lane0 = (g == 0);
 
-    const int qlen = a.quad_qlen[quad];
+    const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);
     const int read = a.order[quad * 4 + slot];
     const int lq = (qlen - 1) / R;  // lane / register holding the last query row (wave-uniform)
     const int rq = (qlen - 1) - lq * R;
+    const int t_begin = sweep_begin(lq);
 
     float x[R];
     load_query_rows<R>(x, a, read, qlen, g);
@@ -223,10 +240,12 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     const int jb = a.chunk_begin[chunk], je = a.chunk_begin[chunk + 1];
     for (int job = jb; job < je; ++job) {
         const int rlen = a.job_len[job];
-        const float *yp = a.ref + a.job_off[job] - g;  // this lane's column at step t is t-g
+        const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
 
-        typename Vec<float, R>::type c;
-        typename Vec<int, R>::type s;
+        // State between phases lives in plain registers; the steady-state loop works on register TUPLES so that the
+        // last-row pick is a single indexed v_mov (see Vec).
+        float c[R];
+        int s[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             c[r] = INFINITY;
@@ -237,50 +256,99 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         float wmin = INFINITY;  // running minimum of the current last-row window
         int wpos = -1, wst = -1;
         int wleft = qlen;
+        int jqv = 0;  // last-row column of the current step, kept in a VGPR for the selects
         float *ckp = nullptr;
         if (!TRACK && T)
             ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * ((R + 1) * 64) + lane;
 
-        const int nsteps = rlen + lq;  // lane lq sees column rlen-1 at step rlen-1+lq
+        // e = steps elapsed since t_begin (multiple of 4); step index t = t_begin + e + u
+        const int e_main = lq - t_begin;          // first block whose steps touch last-row column 0
+        const int e_tail = e_main + (rlen & ~3);  // first block with a ragged end
+        const int rem = rlen & 3;
         float4u ycur = *reinterpret_cast<const float4u *>(yp);
-        for (int t0 = 0; t0 < nsteps; t0 += kStepsPerLoad) {
-            const float4u ynext = *reinterpret_cast<const float4u *>(yp + t0 + kStepsPerLoad);
-            if (!TRACK && T) {
-                // checkpoint k = t0/T of the state BEFORE step t0, for 1 <= k <= (rlen-1)/T
-                if (t0 != 0 && (t0 & (T - 1)) == 0 && t0 < rlen) {
+
+        // windowed first-strict-minimum scan of src/sigfish.c:891-901 for one last-row cell (cl, sl)
+        auto last_row = [&](const float cl, const int sl) {
+            const bool lt = cl < wmin;
+            wmin = lt ? cl : wmin;
+            wpos = lt ? jqv : wpos;
+            if (TRACK) wst = lt ? sl : wst;
+            jqv += 1;
+            if (--wleft == 0) {
+                top.offer(wmin, wpos, wst, job);
+                wmin = INFINITY;
+                wpos = -1;
+                wst = -1;
+                wleft = qlen;
+            }
+        };
+        // checkpoint k = el/T: the state BEFORE step t_begin+el, stored for 1 <= k <= (rlen-1)/T
+        auto is_checkpoint = [&](int el) { return !TRACK && T && el != 0 && (el & (T - 1)) == 0 && el < rlen; };
+
+        int e = 0;
+        // ---- prologue: the last query row has not reached column 0 yet ----
+        for (; e < e_main; e += kStepsPerLoad) {
+            const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+            if (is_checkpoint(e)) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) ckp[r * 64] = c[r];
+                for (int r = 0; r < R; ++r) ckp[r * 64] = c[r];
+                ckp[R * 64] = dprev;
+                ckp += (R + 1) * 64;
+            }
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad; ++u)
+                dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0);
+            ycur = ynext;
+        }
+        // ---- main: every step yields one last-row cell ----
+        {
+            typename Vec<float, R>::type cv;
+            typename Vec<int, R>::type sv;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                cv[r] = c[r];
+                sv[r] = s[r];
+            }
+            for (; e < e_tail; e += kStepsPerLoad) {
+                const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+                if (is_checkpoint(e)) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
                     ckp[R * 64] = dprev;
                     ckp += (R + 1) * 64;
                 }
+#pragma unroll
+                for (int u = 0; u < kStepsPerLoad; ++u) {
+                    dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0);
+                    if (!STD) last_row(cv[rq], TRACK ? sv[rq] : 0);
+                }
+                ycur = ynext;
             }
 #pragma unroll
-            for (int u = 0; u < kStepsPerLoad; ++u) {
-                const int t = t0 + u;
-                dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0);
-                // last query row: windowed first-strict-minimum scan (wave-uniform control flow)
-                const int jq = t - lq;
-                if (jq >= 0 && jq < rlen) {
-                    const float cl = c[rq];
-                    const int sl = TRACK ? s[rq] : 0;
-                    if (!STD) {
-                        const bool lt = cl < wmin;
-                        wmin = lt ? cl : wmin;
-                        wpos = lt ? jq : wpos;
-                        if (TRACK) wst = lt ? sl : wst;
-                        if (--wleft == 0 || jq == rlen - 1) {
-                            top.offer(wmin, wpos, wst, job);
-                            wmin = INFINITY;
-                            wpos = -1;
-                            wst = -1;
-                            wleft = qlen;
-                        }
-                    } else if (jq == rlen - 1) {
-                        top.offer(cl, jq, sl, job);  // std_dtw: the single candidate C[n-1][m-1]
-                    }
+            for (int r = 0; r < R; ++r) {
+                c[r] = cv[r];
+                s[r] = sv[r];
+            }
+        }
+        // ---- tail: rlen % 4 remaining last-row columns ----
+        if (rem) {
+            if (is_checkpoint(e)) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ckp[r * 64] = c[r];
+                ckp[R * 64] = dprev;
+            }
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad - 1; ++u) {
+                if (u < rem) {
+                    dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0);
+                    if (!STD) last_row(pick_chain<R>(c, rq), TRACK ? pick_chain<R>(s, rq) : 0);
                 }
             }
-            ycur = ynext;
+        }
+        if (!STD) {
+            if (wleft != qlen) top.offer(wmin, wpos, wst, job);  // the last, shorter window
+        } else {
+            top.offer(pick_chain<R>(c, rq), rlen - 1, TRACK ? pick_chain<R>(s, rq) : 0, job);  // std_dtw: C[n-1][m-1]
         }
     }
 
@@ -348,6 +416,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     bool done = !(read >= 0 && job >= 0 && end >= 0);
     job = done ? 0 : job;
     const int rlen = a.job_len[job];
+    const int t_begin = sweep_begin(lq);  // same time origin as the fill (checkpoint k = state before step t_begin+k*T)
     const float *ybase = a.ref + a.job_off[job] - g;
     const int t_end = end + lq;  // step at which lane lq evaluates the winning cell
 
@@ -356,7 +425,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     const int nck = T ? (rlen - 1) >> a.ck_shift : 0;  // checkpoints stored for this job
     int k = 0;
     if (T) {
-        const int from = t_end - a.trace_margin;
+        const int from = t_end - a.trace_margin - t_begin;  // steps elapsed since t_begin
         k = from > 0 ? (from >> a.ck_shift) : 0;
         k = k < nck ? k : nck;
     }
@@ -364,7 +433,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     int result = -1;
 
     for (int attempt = 0; attempt < 40; ++attempt) {  // bounded: k reaches 0 after <= 32 halvings
-        const int tb = k << a.ck_shift;               // first step to execute
+        const int tb = t_begin + (k << a.ck_shift);   // first step to execute
         typename Vec<float, R>::type c;
         typename Vec<int, R>::type s;
         float dprev;

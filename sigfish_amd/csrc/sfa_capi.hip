@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -110,7 +111,7 @@ struct sfa_ctx {
     int64_t opt_single_pass = 0;             // 1: one fill with start tracking everywhere (first-round design)
     int64_t opt_ckpt_interval = 0;           // force the checkpoint interval (power of two >= 4); 0 = auto
     int64_t opt_ckpt_budget = 8ll << 30;     // bytes of HBM the checkpoints of one batch may take
-    int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = 2*qlen_max
+    int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
 
     // reference model (immutable after init)
@@ -384,7 +385,8 @@ int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {
             c->total_cols += rl;
         }
     }
-    std::vector<float> packed(total, 0.0f);
+    // +inf padding: cells of columns < 0 (and past the end) evaluate to +inf, see sweep_begin() in the kernels
+    std::vector<float> packed(total, INFINITY);
     for (int32_t j = 0; j < c->n_jobs; ++j) {
         const float *src = (job_strand[j] == '+') ? ref->forward[job_contig[j]] : ref->reverse[job_contig[j]];
         if (!src) return bail(fail(SFA_EINVAL, "missing reference array for contig %d", job_contig[j]));

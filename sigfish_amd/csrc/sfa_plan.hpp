@@ -32,7 +32,7 @@ struct PlanParams {
     bool single_pass = false;
     int64_t ckpt_interval = 0;      // 0 = auto
     int64_t ckpt_budget_bytes = 8ll << 30;
-    int64_t trace_margin = -1;      // -1 = 2 * longest query
+    int64_t trace_margin = -1;      // -1 = longest query + 16
 };
 
 struct PlanClass {
@@ -127,15 +127,16 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // chunk the job list only as far as needed to fill the machine
     p.n_chunks = 1;
     if (n_quads > 0 && n_jobs > 1) {
-        const int64_t target = pp.n_sims * pp.waves_per_simd;
-        p.n_chunks = static_cast<int32_t>(std::min<int64_t>(n_jobs, std::max<int64_t>(1, target / n_quads)));
+        // equal-length tasks finish in rounds; ask for >= 16 rounds so the last, partly filled one costs ~3 %
+        const int64_t target = pp.n_sims * pp.waves_per_simd * 16;
+        p.n_chunks = static_cast<int32_t>(std::min<int64_t>(n_jobs, std::max<int64_t>(1, (target + n_quads - 1) / n_quads)));
     }
     p.chunk_begin.resize(p.n_chunks + 1);
     split_jobs(job_len, total_cols, p.n_chunks, p.chunk_begin.data());
 
     // checkpoint interval
     p.job_ck_off.assign(n_jobs + 1, 0);
-    p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : 2 * maxq);
+    p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + 16);
     if (!pp.single_pass && n_quads > 0) {
         int shift = 10;
         if (pp.ckpt_interval > 0) {

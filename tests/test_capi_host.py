@@ -104,7 +104,7 @@ def test_plan_batch_layout():
     assert info["n_quads"] == len(np.unique(quads))
     assert info["n_classes"] == 4 and info["max_rows_per_lane"] == 32
     assert 1 <= info["n_chunks"] <= 2 and info["n_tasks"] == info["n_quads"] * info["n_chunks"]
-    assert info["ckpt_interval"] == 1024 and info["trace_margin"] == 1024
+    assert info["ckpt_interval"] == 1024 and info["trace_margin"] == 512 + 16
     # long classes come first in task order
     order = np.argsort(used)
     l_sorted = lens[lens > 0][order]
