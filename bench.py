@@ -55,12 +55,16 @@ def main():
     ap.add_argument("--workload", default="ncov_r9_dna_q250")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="also time sfa_align_batch with HOST query/result buffers (PCIe-inclusive; never `value`)")
+    ap.add_argument("--opt", action="append", default=[], help="sfa_set_option key=value (tuning experiments)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     import sigfish_amd as S
+    from sigfish_amd import dist as D
     from sigfish_amd import synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -76,32 +80,14 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- reference event model: built on rank 0, broadcast over RCCL/xGMI, resident in every rank's HBM ----
+    ref = flag = None
     if rank == 0:
         ref, flag, _, _, _ = synth.workload(args.workload, n_reads=8, seed=0)
-    if world > 1:
-        hdr = torch.zeros(4, dtype=torch.int64, device=dev)
-        if rank == 0:
-            rna = ref.reverse is None
-            hdr[:] = torch.tensor([ref.num_ref, int(ref.ref_lengths.sum()), int(rna), flag])
-        dist.broadcast(hdr, 0)
-        num_ref, total, rna, flag = (int(x) for x in hdr.tolist())
-        meta_t = torch.zeros(3 * num_ref, dtype=torch.int32, device=dev)
-        lev_t = torch.zeros(total * (1 if rna else 2), dtype=torch.float32, device=dev)
-        if rank == 0:
-            meta_t[:] = torch.from_numpy(np.concatenate([ref.ref_lengths, ref.st_offset, ref.seq_lengths]))
-            flat = np.concatenate(ref.forward + ([] if rna else ref.reverse))
-            lev_t[:] = torch.from_numpy(flat)
-        dist.broadcast(meta_t, 0)
-        dist.broadcast(lev_t, 0)
-        if rank != 0:
-            m = meta_t.cpu().numpy()
-            lens, offs, seql = m[:num_ref], m[num_ref:2 * num_ref], m[2 * num_ref:]
-            lv = lev_t.cpu().numpy()
-            cuts = np.concatenate([[0], np.cumsum(lens)])
-            fw = [lv[cuts[i]:cuts[i + 1]] for i in range(num_ref)]
-            rv = None if rna else [lv[total + cuts[i]:total + cuts[i + 1]] for i in range(num_ref)]
-            ref = S.RefModel([f"contig{i}" for i in range(num_ref)], seql, lens, offs, fw, rv)
+    ref, flag = D.broadcast_ref(ref, flag, device=dev)
     al = S.Aligner(ref, flag, device=local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        al.set_option(k, int(v))
 
     # ---- this rank's shard of reads: synthetic, generated here, uploaded to HBM before the timed region ----
     q, q_off, _ = synth.make_reads(ref, args.reads, qlen=250, seed=1000 + rank)
@@ -113,7 +99,7 @@ def main():
     alg_bytes = int((4 * lens + 4 * cols + 32).sum())
     d_q = torch.from_numpy(q).to(dev)
     d_out = torch.zeros(n * S.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(d_out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    counts = [n] * world
     torch.cuda.synchronize()
 
     fill_ms, trace_ms, launches = [], [], 0
@@ -126,8 +112,8 @@ def main():
             fill_ms.append(p["fill_ms"])
             trace_ms.append(p["trace_ms"])
             launches += p["fill_launches"]
-        if world > 1:  # final gather of the result rows (24 B/read) to rank 0
-            dist.gather(d_out, gathered, dst=0)
+        if world > 1:  # final gather of the result rows (24 B/read) to rank 0, in read order
+            D.gather_rows(d_out, counts)
 
     for _ in range(args.warmup):
         step(False)
@@ -187,6 +173,13 @@ def main():
                      "frac": round(cells_per_s_kernel * ops_per_cell / VALU_LANE_OPS, 4)},
         },
     }
+
+    if args.host_buffers and world == 1:
+        al.align_db(q, q_off)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            al.align_db(q, q_off)
+        out["pcie_inclusive_reads_per_s"] = round(n * args.steps / (time.perf_counter() - t1), 1)
 
     # ---- CPU baseline: the oracle on a bounded sample of this rank's reads, all host cores -----------------
     if world == 1 and not args.no_cpu_baseline:
