@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsigfish_amd.so")
+LIB_PATH = os.environ.get("SFA_LIB") or os.path.join(HERE, "lib", "libsigfish_amd.so")  # SFA_LIB: A/B builds
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)

@@ -39,11 +39,17 @@ namespace sfa {
 constexpr int kLanesPerRead = 16;  // one DPP row
 constexpr int kReadsPerWave = 4;
 constexpr int kRefPad = 64;        // floats of padding on both sides of every (contig,strand) array in HBM
-constexpr int kStepsPerLoad = 4;   // reference levels fetched per 16-byte load
+#ifndef SFA_STEPS_PER_LOAD
+#define SFA_STEPS_PER_LOAD 4
+#endif
+#ifndef SFA_FILL_WAVES
+#define SFA_FILL_WAVES 6  // waves per SIMD the cost-only fill (R <= 16) is register-budgeted for: 80 VGPRs
+#endif
+constexpr int kStepsPerLoad = SFA_STEPS_PER_LOAD;  // reference levels fetched per load (4 = one 16-byte load)
 constexpr int kMaxClasses = 4;     // query-length classes R = 32, 16, 8, 4
 
 struct __attribute__((packed, aligned(4))) float4u {
-    float v[4];
+    float v[kStepsPerLoad];
 };
 
 // A query-length class inside one launch.
@@ -210,7 +216,7 @@ __device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, 
 // t_begin = lq - roundup4(lq) in (-4, 0]: the first roundup4(lq) steps are a prologue with no last-row work, and
 // from then on block b covers last-row columns 4b..4b+3 with no per-step range checks.  Columns < 0 read the
 // +inf padding in front of every reference array, which keeps those cells at +inf.
-__device__ __forceinline__ int sweep_begin(int lq) { return lq - ((lq + 3) & ~3); }
+__device__ __forceinline__ int sweep_begin(int lq) { return lq - ((lq + kStepsPerLoad - 1) & ~(kStepsPerLoad - 1)); }
 
 template <int R, bool TRACK, bool STD>
 __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local) {
@@ -263,8 +269,8 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
 
         // e = steps elapsed since t_begin (multiple of 4); step index t = t_begin + e + u
         const int e_main = lq - t_begin;          // first block whose steps touch last-row column 0
-        const int e_tail = e_main + (rlen & ~3);  // first block with a ragged end
-        const int rem = rlen & 3;
+        const int e_tail = e_main + (rlen & ~(kStepsPerLoad - 1));  // first block with a ragged end
+        const int rem = rlen & (kStepsPerLoad - 1);
         float4u ycur = *reinterpret_cast<const float4u *>(yp);
 
         // windowed first-strict-minimum scan of src/sigfish.c:891-901 for one last-row cell (cl, sl)
@@ -274,7 +280,11 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
             wpos = lt ? jqv : wpos;
             if (TRACK) wst = lt ? sl : wst;
             jqv += 1;
-            if (--wleft == 0) {
+#ifdef SFA_EXP_NOWINDOW
+            if (false) {
+#else
+            if (__builtin_expect(--wleft == 0, 0)) {
+#endif
                 top.offer(wmin, wpos, wst, job);
                 wmin = INFINITY;
                 wpos = -1;
@@ -365,7 +375,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
 // grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR bounds the classes compiled in,
 // so a batch without long queries does not pay the long variant's register budget.
 template <int MAXR, bool TRACK, bool STD>
-__global__ void __launch_bounds__(256) sdtw_fill_kernel(const DpArgs a) {
+__global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES : 1) sdtw_fill_kernel(const DpArgs a) {
     const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
     if (task >= a.n_tasks) return;  // wave-uniform
