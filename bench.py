@@ -145,7 +145,7 @@ def main():
     launches_per_step = max(launches // max(args.steps, 1), 1)
     achieved = alg_bytes / kern_s / 1e9
     cells_per_s_kernel = cells / kern_s
-    ops_per_cell = 3.3  # counted from the shipped R=16 fill ISA: 3 per cell + ~5 per 16-cell step
+    ops_per_cell = 3.375  # counted from the shipped R=16 fill ISA: 54 VALU per 16-cell step
     out = {
         "metric": "reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)",
         "value": round(value, 1),
