@@ -165,6 +165,33 @@ int sfa_paf_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_i
                 uint64_t start_raw_idx, uint64_t end_raw_idx, uint64_t query_size, uint64_t len_raw_signal,
                 uint64_t rlength);
 
+/* ---- host pre-DP stages and readers (no GPU needed) ----------------------------- */
+
+/* event_single (src/sigfish.c:330-378): raw ADC samples -> pA -> events (getevents, src/events.c:557-577).
+ * Writes at most cap events to out; returns the number of events detected (call again with a larger buffer if
+ * the return value exceeds cap), or <0 on error. */
+int64_t sfa_detect_events(const int16_t *raw, int64_t n_raw, double digitisation, double offset, double range, int rna,
+                          sfa_event_t *out, int64_t cap);
+
+/* normalise_single (src/sigfish.c:424-505): choose the query window [qstart,qend) from -p/-q/--from-end
+ * (prefix_size < 0: RNA adaptor/poly-A auto detection, src/sigfish.c:380-422 + src/jnn.c) and z-normalise those
+ * event means in place.  Returns 1 if the read is kept, 0 if the reference would drop it (et.n = 0). */
+int sfa_select_query(sfa_event_t *events, int64_t n_events, const int16_t *raw, int64_t n_raw, double digitisation,
+                     double offset, double range, int32_t prefix_size, int32_t query_size, uint32_t flag, int pore,
+                     int64_t *qstart, int64_t *qend);
+
+/* read_model (src/model.c:38-131): text k-mer model -> level_mean[4^k] (levels must hold 262144 floats). */
+int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k);
+
+/* Sequential BLOW5 reader (zlib / svb-zd / uncompressed), the subset of slow5lib the path uses. */
+typedef struct sfa_blow5 sfa_blow5_t;
+sfa_blow5_t *sfa_blow5_open(const char *path);            /* NULL on failure, see sfa_last_error() */
+const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key); /* header attribute of read group 0 or NULL */
+/* 1: a record was read, 0: end of file, <0: error.  Pointers stay valid until the next call on f.
+ * meta = {digitisation, offset, range, sampling_rate}. */
+int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const int16_t **raw, int64_t *n_raw);
+void sfa_blow5_close(sfa_blow5_t *f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,3 +229,79 @@ def paf_row(res, read_id, rname, start_raw, end_raw, query_size, len_raw, rlengt
     if n < 0:
         raise SfaError("sfa_paf_row: buffer too small")
     return buf.raw[:n].decode()
+
+
+# ---- host pre-DP stages and readers ------------------------------------------------------------
+class Blow5File:
+    """Sequential BLOW5 reader: iterates (read_id, meta dict, raw int16 array)."""
+
+    def __init__(self, path):
+        self._L = _lib.load()
+        self._h = self._L.sfa_blow5_open(str(path).encode())
+        if not self._h:
+            raise SfaError(self._L.sfa_last_error().decode())
+
+    def attr(self, key):
+        v = self._L.sfa_blow5_attr(self._h, key.encode())
+        return None if v is None else v.decode()
+
+    def __iter__(self):
+        rid = C.c_char_p()
+        meta = (C.c_double * 4)()
+        raw = C.POINTER(C.c_int16)()
+        n = C.c_int64()
+        while True:
+            rc = self._L.sfa_blow5_next(self._h, C.byref(rid), meta, C.byref(raw), C.byref(n))
+            if rc == 0:
+                return
+            if rc < 0:
+                raise SfaError(self._L.sfa_last_error().decode())
+            sig = np.ctypeslib.as_array(raw, (n.value,)).copy() if n.value else np.zeros(0, np.int16)
+            yield rid.value.decode(), dict(digitisation=meta[0], offset=meta[1], range=meta[2], sampling_rate=meta[3]), sig
+
+    def close(self):
+        if self._h:
+            self._L.sfa_blow5_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def detect_events(raw, meta, rna=False):
+    """event_single: raw int16 samples + scaling -> EVENT_DTYPE array."""
+    raw = np.ascontiguousarray(raw, np.int16)
+    L = _lib.load()
+    cap = max(len(raw) // 2, 16)
+    out = np.zeros(cap, EVENT_DTYPE)
+    n = L.sfa_detect_events(raw.ctypes.data_as(C.POINTER(C.c_int16)), len(raw), meta["digitisation"], meta["offset"],
+                            meta["range"], int(rna), C.cast(out.ctypes.data, C.POINTER(_lib.SfaEvent)), cap)
+    if n < 0:
+        raise SfaError("sfa_detect_events failed")
+    if n > cap:
+        out = np.zeros(n, EVENT_DTYPE)
+        n = L.sfa_detect_events(raw.ctypes.data_as(C.POINTER(C.c_int16)), len(raw), meta["digitisation"], meta["offset"],
+                                meta["range"], int(rna), C.cast(out.ctypes.data, C.POINTER(_lib.SfaEvent)), n)
+    return out[:n]
+
+
+def select_query(events, raw, meta, prefix_size=50, query_size=250, flag=0, pore=0):
+    """normalise_single: returns (keep, qstart, qend); `events` is normalised in place over [qstart,qend)."""
+    raw = np.ascontiguousarray(raw, np.int16)
+    qs, qe = C.c_int64(), C.c_int64()
+    keep = _lib.load().sfa_select_query(C.cast(events.ctypes.data, C.POINTER(_lib.SfaEvent)), len(events),
+                                        raw.ctypes.data_as(C.POINTER(C.c_int16)), len(raw), meta["digitisation"],
+                                        meta["offset"], meta["range"], prefix_size, query_size, flag, pore,
+                                        C.byref(qs), C.byref(qe))
+    return bool(keep), qs.value, qe.value
+
+
+def read_kmer_model(path):
+    lv = np.zeros(262144, np.float32)
+    k = C.c_uint32()
+    _check(_lib.load().sfa_read_kmer_model(str(path).encode(), lv.ctypes.data_as(_lib.f32p), C.byref(k)),
+           "sfa_read_kmer_model")
+    return lv[:4 ** k.value].copy(), k.value

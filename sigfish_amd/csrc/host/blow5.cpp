@@ -1,0 +1,189 @@
+// blow5.cpp -- see blow5.hpp.  zlib is the only dependency (zstd-compressed files are rejected with a message,
+// like a reference binary built without zstd=1).
+#include "blow5.hpp"
+
+#include <zlib.h>
+
+#include <cstring>
+
+namespace sfa {
+
+namespace {
+const unsigned char kMagic[6] = {'B', 'L', 'O', 'W', '5', 1};
+const unsigned char kEof[5] = {'5', 'W', 'O', 'L', 'B'};
+
+template <typename T>
+bool take(const uint8_t *&p, const uint8_t *end, T *out) {
+    if (static_cast<size_t>(end - p) < sizeof(T)) return false;
+    memcpy(out, p, sizeof(T));
+    p += sizeof(T);
+    return true;
+}
+
+bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> *dst) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, MAX_WBITS) != Z_OK) return false;
+    dst->resize(std::max<size_t>(n * 4, 1 << 16));
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = static_cast<uInt>(n);
+    size_t have = 0;
+    int rc;
+    do {
+        if (have == dst->size()) dst->resize(dst->size() * 2);
+        zs.next_out = dst->data() + have;
+        zs.avail_out = static_cast<uInt>(dst->size() - have);
+        rc = inflate(&zs, Z_NO_FLUSH);
+        have = dst->size() - zs.avail_out;
+    } while (rc == Z_OK);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    dst->resize(have);
+    return true;
+}
+
+// StreamVByte (scalar form) + zig-zag delta -> int16 samples
+bool decode_svb_zd(const uint8_t *p, size_t nbytes, std::vector<int16_t> *out) {
+    if (nbytes < 4) return false;
+    uint32_t n;
+    memcpy(&n, p, 4);
+    const uint8_t *keys = p + 4;
+    const size_t nkeys = (static_cast<size_t>(n) + 3) / 4;
+    if (4 + nkeys > nbytes) return false;
+    const uint8_t *data = keys + nkeys;
+    const uint8_t *end = p + nbytes;
+    out->resize(n);
+    int32_t prev = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const unsigned code = (keys[i >> 2] >> ((i & 3) * 2)) & 3u;  // bytes-1 of value i
+        if (static_cast<size_t>(end - data) < code + 1) return false;
+        uint32_t v = 0;
+        memcpy(&v, data, code + 1);  // little endian
+        data += code + 1;
+        const int32_t delta = static_cast<int32_t>(v >> 1) ^ -static_cast<int32_t>(v & 1);
+        (*out)[i] = static_cast<int16_t>(delta + prev);
+        prev += delta;
+    }
+    return data == end;
+}
+}  // namespace
+
+void Blow5Reader::close() {
+    if (fp_) fclose(fp_);
+    fp_ = nullptr;
+}
+
+const char *Blow5Reader::attr(const std::string &key) const {
+    auto it = attrs_.find(key);
+    return it == attrs_.end() ? nullptr : it->second.c_str();
+}
+
+bool Blow5Reader::open(const std::string &path) {
+    close();
+    attrs_.clear();
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_) {
+        err_ = "cannot open " + path;
+        return false;
+    }
+    unsigned char head[68];
+    if (fread(head, 1, sizeof head, fp_) != sizeof head || memcmp(head, kMagic, sizeof kMagic) != 0) {
+        err_ = path + ": not a BLOW5 file (bad magic number)";
+        return false;
+    }
+    const unsigned major = head[6], minor = head[7];
+    record_press_ = head[9];
+    memcpy(&n_groups_, head + 10, 4);
+    signal_press_ = (major > 0 || minor >= 2) ? head[14] : 0;
+    uint32_t hsize;
+    memcpy(&hsize, head + 64, 4);
+    std::string text(hsize, '\0');
+    if (hsize && fread(&text[0], 1, hsize, fp_) != hsize) {
+        err_ = path + ": truncated BLOW5 header";
+        return false;
+    }
+    if (record_press_ > 1) {
+        err_ = path + ": record compression method " + std::to_string(record_press_) + " is not supported (zlib or none only)";
+        return false;
+    }
+    if (signal_press_ > 1) {
+        err_ = path + ": signal compression method " + std::to_string(signal_press_) + " is not supported (svb-zd or none only)";
+        return false;
+    }
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        if (text[pos] == '@') {
+            const size_t tab = text.find('\t', pos);
+            if (tab != std::string::npos && tab < eol) {
+                size_t vend = text.find('\t', tab + 1);  // value of read group 0
+                if (vend == std::string::npos || vend > eol) vend = eol;
+                attrs_[text.substr(pos + 1, tab - pos - 1)] = text.substr(tab + 1, vend - tab - 1);
+            }
+        }
+        pos = eol + 1;
+    }
+    return true;
+}
+
+int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
+    if (!fp_) return -1;
+    uint64_t size = 0;
+    const size_t got = fread(&size, 1, sizeof size, fp_);
+    if (got != sizeof size) {
+        if (got == sizeof kEof && memcmp(&size, kEof, sizeof kEof) == 0) return 0;
+        err_ = "malformed BLOW5: missing end-of-file marker";
+        return -1;
+    }
+    mem->resize(size);
+    if (size && fread(mem->data(), 1, size, fp_) != size) {
+        err_ = "malformed BLOW5: truncated record";
+        return -1;
+    }
+    return 1;
+}
+
+bool Blow5Reader::parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::string *err) const {
+    rec->record_bytes = mem.size();
+    std::vector<uint8_t> inflated;
+    const uint8_t *p = mem.data(), *end = p + mem.size();
+    if (record_press_ == 1) {
+        if (!inflate_all(mem.data(), mem.size(), &inflated)) {
+            *err = "malformed BLOW5: record does not inflate";
+            return false;
+        }
+        p = inflated.data();
+        end = p + inflated.size();
+    }
+    uint16_t idlen;
+    uint64_t len;
+    bool ok = take(p, end, &idlen) && static_cast<size_t>(end - p) >= idlen;
+    if (ok) {
+        rec->read_id.assign(reinterpret_cast<const char *>(p), idlen);
+        p += idlen;
+        ok = take(p, end, &rec->read_group) && take(p, end, &rec->digitisation) && take(p, end, &rec->offset) &&
+             take(p, end, &rec->range) && take(p, end, &rec->sampling_rate) && take(p, end, &len);
+    }
+    if (ok) {
+        if (signal_press_ == 0) {
+            ok = static_cast<uint64_t>(end - p) >= len * 2;
+            if (ok) {
+                rec->raw.resize(len);
+                memcpy(rec->raw.data(), p, len * 2);
+            }
+        } else {
+            ok = static_cast<uint64_t>(end - p) >= len && decode_svb_zd(p, len, &rec->raw);
+        }
+    }
+    if (!ok) *err = "malformed BLOW5 record (read " + rec->read_id + ")";
+    return ok;
+}
+
+int Blow5Reader::next(Blow5Record *rec) {
+    const int rc = next_mem(&buf_);
+    if (rc <= 0) return rc;
+    return parse(buf_, rec, &err_) ? 1 : -1;
+}
+
+}  // namespace sfa

@@ -1,0 +1,55 @@
+// blow5.hpp -- minimal sequential BLOW5 reader: just what the `dtw` path consumes.
+//
+// On-disk layout (slow5 spec 0.2.0; reference reader: slow5lib/src/slow5.c:792-835 header, 3218-3266 record
+// framing, 2806-2925 primary fields; slow5lib/src/slow5_press.c:76-146 method codes, 1085-1135 svb-zd):
+//   magic "BLOW5\1" | version u8[3] | record_press u8 | num_read_groups u32 | signal_press u8 (>= 0.2.0) |
+//   zero pad to byte 64 | ascii_header_size u32 | ascii header ("@attr\tv0[\tv1..]" lines, "#types", "#names") |
+//   records: [u64 size][payload] ... | EOF marker "5WOLB"
+//   payload (after inflating the whole record when record_press == zlib):
+//   u16 id_len, id, u32 read_group, f64 digitisation, f64 offset, f64 range, f64 sampling_rate, u64 len,
+//   signal bytes, auxiliary fields (ignored here).  With signal_press == svb-zd, `len` is the compressed byte
+//   count and the signal is u32 n + StreamVByte(keys ceil(n/4) B, data 1-4 B little endian) of zig-zag deltas.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace sfa {
+
+struct Blow5Record {
+    std::string read_id;
+    uint32_t read_group = 0;
+    double digitisation = 0, offset = 0, range = 0, sampling_rate = 0;
+    std::vector<int16_t> raw;
+    uint64_t record_bytes = 0;  // on-disk payload size (the reference's -B accounting, sigfish.c:304)
+};
+
+class Blow5Reader {
+  public:
+    ~Blow5Reader() { close(); }
+    // returns false and sets error() on failure
+    bool open(const std::string &path);
+    void close();
+    // 1: record read, 0: clean end of file (EOF marker seen), -1: error
+    int next(Blow5Record *rec);
+    // the two halves of next(), so that decompression can run on worker threads (the reference does the same:
+    // slow5_get_next_mem in load_db, slow5_rec_depress_parse in parse_single, src/sigfish.c:289,322)
+    int next_mem(std::vector<uint8_t> *mem);
+    bool parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::string *err) const;
+    // first value (read group 0) of a header attribute, or nullptr (slow5_hdr_get(attr, 0, hdr))
+    const char *attr(const std::string &key) const;
+    uint32_t num_read_groups() const { return n_groups_; }
+    const std::string &error() const { return err_; }
+
+  private:
+    FILE *fp_ = nullptr;
+    uint8_t record_press_ = 0, signal_press_ = 0;
+    uint32_t n_groups_ = 1;
+    std::map<std::string, std::string> attrs_;
+    std::string err_;
+    std::vector<uint8_t> buf_, inflated_;
+};
+
+}  // namespace sfa

@@ -1,0 +1,344 @@
+// dtw_main.cpp -- `sigfish-amd dtw`: the reference's `sigfish dtw` command line (src/dtw_main.c:125-352) over the
+// MI355X alignment stage.  Same positional arguments, options and PAF output; the batch loop keeps the reference's
+// order (load -> process -> output, src/dtw_main.c:299-326) so reads come out in file order.
+//
+// Host stages run on a thread fan-out per batch (parse, events, normalise: src/sigfish.c:317-505); the DTW stage
+// is one call into the C-ABI (sfa_align_events, the align_db hook).  There is no CPU DTW path in this binary.
+#include <getopt.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/sigfish_amd.h"
+#include "blow5.hpp"
+#include "events.hpp"
+#include "refio.hpp"
+
+namespace {
+
+// option bits beyond the ones the library reads: same values as src/sigfish.h:30-39
+enum : uint32_t { F_RNA = 0x001, F_DTW = 0x002, F_INV = 0x004, F_SEC = 0x008, F_REF = 0x010, F_END = 0x020, F_PRF = 0x040, F_SAM = 0x100, F_R10 = 0x200 };
+
+struct Opt {
+    uint32_t flag = 0;
+    int32_t batch_size = 4096;            // -K  (reference default 512; a GPU batch wants thousands of reads)
+    int64_t batch_bytes = 200 * 1000 * 1000;  // -B  (reference default 20M)
+    int32_t threads = 8;
+    int32_t prefix = 50, query = 250;
+    int32_t debug_break = -1;
+    int verbosity = 4;
+    int device = 0;
+    const char *model_file = nullptr;
+    const char *pore = nullptr;
+    int pore_flag = 0;  // 0 r9, 1 r10, 2 rna004
+};
+
+double realtime() {
+    timeval tv;
+    gettimeofday(&tv, nullptr);
+    return tv.tv_sec + tv.tv_usec * 1e-6;
+}
+double cputime() {
+    rusage r;
+    getrusage(RUSAGE_SELF, &r);
+    return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+
+[[noreturn]] void die(const std::string &msg) {
+    fprintf(stderr, "[sigfish-amd] ERROR: %s\n", msg.c_str());
+    exit(EXIT_FAILURE);
+}
+
+int64_t parse_num(const char *s) {  // K/M/G suffixes as src/dtw_main.c:46-58
+    char *e;
+    double x = strtod(s, &e);
+    if (*e == 'G' || *e == 'g')
+        x *= 1e9;
+    else if (*e == 'M' || *e == 'm')
+        x *= 1e6;
+    else if (*e == 'K' || *e == 'k')
+        x *= 1e3;
+    return static_cast<int64_t>(x + .499);
+}
+
+void help(FILE *fp, const Opt &o) {
+    fprintf(fp, "Usage: sigfish-amd dtw [OPTIONS] genome.fa reads.blow5\n\nbasic options:\n");
+    fprintf(fp, "   -t INT                     number of host threads for parsing and event detection [%d]\n", o.threads);
+    fprintf(fp, "   -K INT                     batch size (max number of reads loaded at once) [%d]\n", o.batch_size);
+    fprintf(fp, "   -B FLOAT[K/M/G]            max number of bytes loaded at once [%.1fM]\n", o.batch_bytes / 1e6);
+    fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
+    fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
+    fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
+    fprintf(fp, "   --device INT               GPU to use [0]\n\nadvanced options:\n");
+    fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
+    fprintf(fp, "   --rna                      the dataset is direct RNA\n");
+    fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
+    fprintf(fp, "   -p INT                     the number of events to trim at query signal start [%d]\n", o.prefix);
+    fprintf(fp, "   --debug-break INT          break after processing the specified no. of batches\n");
+    fprintf(fp, "   --dtw-std                  use DTW standard instead of DTW subsequence\n");
+    fprintf(fp, "   --invert                   reverse the reference events instead of query\n");
+    fprintf(fp, "   --full-ref                 map to the full reference\n");
+    fprintf(fp, "   --from-end                 map the end portion of the query instead of the beginning\n");
+}
+
+struct Read {
+    std::vector<uint8_t> mem;
+    sfa::Blow5Record rec;
+    std::vector<sfa_event_t> ev;
+    int64_t qstart = 0, qend = 0;
+    bool keep = false;
+    int status = 0;
+};
+
+template <typename F>
+void parallel_for(int64_t n, int nthreads, F fn) {  // work_db(): one fan-out per stage, atomic work queue
+    if (nthreads <= 1 || n <= 1) {
+        for (int64_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> pool;
+    const int nt = static_cast<int>(std::min<int64_t>(nthreads, n));
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&] {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i);
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+int dtw_main(int argc, char **argv) {
+    const double t0 = realtime();
+    static option lo[] = {{"threads", required_argument, 0, 't'},   {"batchsize", required_argument, 0, 'K'},
+                          {"max-bytes", required_argument, 0, 'B'}, {"verbose", required_argument, 0, 'v'},
+                          {"help", no_argument, 0, 'h'},            {"version", no_argument, 0, 'V'},
+                          {"kmer-model", required_argument, 0, 1},  {"output", required_argument, 0, 'o'},
+                          {"rna", no_argument, 0, 2},               {"prefix", required_argument, 0, 'p'},
+                          {"query-size", required_argument, 0, 'q'}, {"debug-break", required_argument, 0, 3},
+                          {"dtw-std", no_argument, 0, 4},           {"invert", no_argument, 0, 5},
+                          {"full-ref", no_argument, 0, 6},          {"from-end", no_argument, 0, 7},
+                          {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
+                          {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
+                          {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},
+                          {0, 0, 0, 0}};
+    Opt o;
+    FILE *fp_help = stderr;
+    int c, li = 0;
+    while ((c = getopt_long(argc, argv, "p:q:t:B:K:v:o:w:ahV", lo, &li)) >= 0) {
+        switch (c) {
+            case 'B': o.batch_bytes = parse_num(optarg); if (o.batch_bytes <= 0) die("Maximum number of bytes should be larger than 0."); break;
+            case 'K': o.batch_size = atoi(optarg); if (o.batch_size < 1) die("Batch size should larger than 0."); break;
+            case 't': o.threads = atoi(optarg); if (o.threads < 1) die("Number of threads should larger than 0."); break;
+            case 'v': o.verbosity = atoi(optarg); break;
+            case 'V': fprintf(stdout, "sigfish-amd %s\n", sfa_version()); exit(EXIT_SUCCESS);
+            case 'h': fp_help = stdout; break;
+            case 'p': o.prefix = atoi(optarg); break;
+            case 'q': o.query = atoi(optarg); if (o.query < 0) die("Query size should larger than 0."); break;
+            case 'o': if (strcmp(optarg, "-") != 0 && !freopen(optarg, "wb", stdout)) die(std::string("failed to write the output to file ") + optarg); break;
+            case 'a': o.flag |= F_SAM; break;
+            case 'w': break;  // parsed and unused by the reference as well
+            case 1: o.model_file = optarg; break;
+            case 2: o.flag |= F_RNA; break;
+            case 3: o.debug_break = atoi(optarg); break;
+            case 4: o.flag |= F_DTW; break;
+            case 5: o.flag |= F_INV; break;
+            case 6: o.flag |= F_REF; break;
+            case 7: o.flag |= F_END; break;
+            case 8: case 9: case 12: case 13: break;  // CPU profiling / accel toggles / dead options: accepted, no effect
+            case 10:
+                o.pore = optarg;
+                if (strcmp(optarg, "r9") && strcmp(optarg, "r10") && strcmp(optarg, "rna004")) die("Pore model should be r9, r10 or rna004");
+                if (!strcmp(optarg, "r10")) { o.flag |= F_R10; o.pore_flag = 1; }
+                if (!strcmp(optarg, "rna004")) { o.flag |= F_RNA | F_R10; o.pore_flag = 2; }
+                break;
+            case 11: o.device = atoi(optarg); break;
+            default: help(stderr, o); exit(EXIT_FAILURE);
+        }
+    }
+    if (argc - optind != 2 || fp_help == stdout) {
+        help(fp_help, o);
+        exit(fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE);
+    }
+    const char *fasta = argv[optind], *blow5 = argv[optind + 1];
+    // same order of checks as src/dtw_main.c:248-277 (before RNA auto-detection)
+    if (!(o.flag & F_RNA)) {
+        if (o.flag & F_DTW) die("DTW is only available for RNA.");
+        if (o.flag & F_INV) die("Inversion is only available for RNA.");
+        if (o.flag & F_REF) die("--full-ref is only available for RNA.");
+    }
+    if (o.prefix < 0) {
+        if (!(o.flag & F_RNA)) die("DNA does not support auto query start detection.");
+        if (o.flag & F_INV) die("Inversion is not compatible with auto query start detection.");
+        if (o.flag & F_END) die("Mapping from query end is not compatible with auto query start detection.");
+    }
+    if (o.flag & F_SAM) die("--sam is not available in this build yet (PAF only)");
+
+    // ---- init_core(), src/sigfish.c:81-207 ----
+    sfa::Blow5Reader reader;
+    if (!reader.open(blow5)) die(reader.error());
+    if (const char *exp = reader.attr("experiment_type")) {
+        if (!strcmp(exp, "rna")) o.flag |= F_RNA;
+    }
+    if (!o.pore) {
+        if (const char *kit = reader.attr("sequencing_kit")) {
+            if (strstr(kit, "114")) { o.flag |= F_R10; o.pore_flag = 1; }
+            else if (strstr(kit, "rna004")) { o.flag |= F_R10; o.pore_flag = 2; }
+            if (o.pore_flag == 1 && (o.flag & F_RNA)) die("R10 RNA data does not exist! But the header indicates that the data is R10 RNA.");
+        }
+    }
+    const bool rna = (o.flag & F_RNA) != 0;
+    if (!o.model_file)
+        die("builtin pore models are not bundled with this build (the reference's src/model.h tables are not part of "
+            "this tree); pass --kmer-model FILE");
+    std::vector<float> levels;
+    uint32_t k = 0;
+    std::string err;
+    if (!sfa::read_kmer_model(o.model_file, &levels, &k, &err)) die(err);
+    std::vector<sfa::FastaRecord> contigs;
+    if (!sfa::read_fasta(fasta, &contigs, &err)) die(err);
+    if (contigs.empty()) die(std::string("no sequences in ") + fasta);
+    const int32_t nref = static_cast<int32_t>(contigs.size());
+    std::vector<std::vector<float>> fwd(nref), rev(nref);
+    std::vector<int32_t> ref_len(nref), ref_off(nref), seq_len(nref);
+    for (int32_t i = 0; i < nref; ++i) {
+        const int32_t l = static_cast<int32_t>(contigs[i].seq.size());
+        if (l < static_cast<int32_t>(k)) die("contig " + contigs[i].name + " is shorter than the k-mer size");
+        fwd[i].resize(l + 1 - k);
+        if (!rna) rev[i].resize(l + 1 - k);
+        const int32_t n = sfa_gen_ref_record(contigs[i].seq.c_str(), l, levels.data(), k, o.flag, o.query, fwd[i].data(),
+                                             rna ? nullptr : rev[i].data(), &ref_off[i]);
+        if (n <= 0) die("cannot build reference events for " + contigs[i].name);
+        ref_len[i] = n;
+        seq_len[i] = l;
+    }
+    std::vector<const float *> fp(nref), rp(nref);
+    for (int32_t i = 0; i < nref; ++i) {
+        fp[i] = fwd[i].data();
+        rp[i] = rna ? nullptr : rev[i].data();
+    }
+    sfa_ref_t sref{nref, ref_len.data(), ref_off.data(), fp.data(), rna ? nullptr : rp.data()};
+    sfa_ctx_t *ctx = nullptr;
+    if (sfa_init(&ctx, &sref, o.flag, o.device) != SFA_OK) die(std::string("accelerator init failed: ") + sfa_last_error());
+
+    // ---- batch loop, src/dtw_main.c:299-326 ----
+    double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
+    int64_t total = 0, prefix_fail = 0, ignored = 0, too_short = 0, sum_bytes = 0;
+    std::vector<Read> batch(o.batch_size);
+    std::vector<const sfa_event_t *> evp(o.batch_size);
+    std::vector<int64_t> nev(o.batch_size), qs(o.batch_size), qe(o.batch_size);
+    std::vector<sfa_result_t> rows(o.batch_size);
+    std::string line(4096, '\0');
+    int32_t counter = 0;
+    bool more = true;
+    while (more) {
+        double a = realtime();
+        int32_t n = 0;
+        int64_t bytes = 0;
+        while (n < o.batch_size && bytes < o.batch_bytes) {
+            const int rc = reader.next_mem(&batch[n].mem);
+            if (rc < 0) die(reader.error());
+            if (rc == 0) {
+                more = false;
+                break;
+            }
+            bytes += static_cast<int64_t>(batch[n].mem.size());
+            ++n;
+        }
+        t_load += realtime() - a;
+        if (o.verbosity >= 4)
+            fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
+        a = realtime();
+        std::atomic<int> bad(0);
+        parallel_for(n, o.threads, [&](int64_t i) {
+            Read &r = batch[i];
+            std::string perr;
+            if (!reader.parse(r.mem, &r.rec, &perr)) {
+                bad = 1;
+                return;
+            }
+            r.keep = false;
+            r.ev.clear();
+            r.status = 0;
+            const int64_t ns = static_cast<int64_t>(r.rec.raw.size());
+            if (ns > 0) {  // event_single + normalise_single
+                std::vector<float> pa(ns);
+                sfa::raw_to_picoamps(r.rec.raw.data(), ns, r.rec.digitisation, r.rec.offset, r.rec.range, pa.data());
+                r.ev = sfa::detect_events(pa.data(), ns, rna);
+                if (!r.ev.empty())
+                    r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), ns, pa.data(), o.prefix, o.query, o.flag, o.pore_flag,
+                                                       &r.qstart, &r.qend, &r.status);
+            }
+        });
+        if (bad) die("error parsing a BLOW5 record");
+        for (int32_t i = 0; i < n; ++i) {
+            const Read &r = batch[i];
+            evp[i] = r.keep ? r.ev.data() : nullptr;
+            nev[i] = r.keep ? static_cast<int64_t>(r.ev.size()) : 0;
+            qs[i] = r.qstart;
+            qe[i] = r.qend;
+            prefix_fail += (r.status & 4) != 0;
+            ignored += (r.status & 2) != 0;
+            too_short += (r.status & 1) != 0;
+        }
+        t_proc += realtime() - a;
+        a = realtime();
+        if (n > 0 && sfa_align_events(ctx, evp.data(), nev.data(), qs.data(), qe.data(), n, rows.data()) != SFA_OK)
+            die(std::string("alignment failed: ") + sfa_last_error());
+        t_dtw += realtime() - a;
+        if (o.verbosity >= 4)
+            fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) processed\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
+        a = realtime();
+        for (int32_t i = 0; i < n; ++i) {  // output_db + aln_to_str, src/sigfish.c:796-826,1051-1086
+            const Read &r = batch[i];
+            if (!r.keep || !rows[i].valid || rows[i].rid < 0) continue;
+            const sfa_event_t &e0 = r.ev[r.qstart], &e1 = r.ev[r.qend - 1];
+            const uint64_t start_raw = e0.start;
+            const uint64_t end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
+            const int len = sfa_paf_row(&line[0], line.size(), &rows[i], r.rec.read_id.c_str(), contigs[rows[i].rid].name.c_str(), start_raw,
+                                        end_raw, static_cast<uint64_t>((r.qend - 1) - r.qstart), r.rec.raw.size(),
+                                        static_cast<uint64_t>(seq_len[rows[i].rid]));
+            if (len < 0) die("PAF line too long");
+            fwrite(line.data(), 1, len, stdout);
+        }
+        fflush(stdout);
+        t_out += realtime() - a;
+        total += n;
+        sum_bytes += bytes;
+        if (o.debug_break == counter) break;
+        ++counter;
+    }
+    sfa_destroy(ctx);
+    if (o.verbosity >= 3) {
+        fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld\n", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);
+        fprintf(stderr, "[dtw_main] total bytes: %.1f M\n[dtw_main] Data loading time: %.3f sec\n", sum_bytes / 1e6, t_load);
+        fprintf(stderr, "[dtw_main] Data processing time: %.3f sec\n[dtw_main]     - Parse+Events+Normalise time: %.3f sec\n[dtw_main]     - DTW time: %.3f sec\n",
+                t_proc + t_dtw, t_proc, t_dtw);
+        fprintf(stderr, "[dtw_main] Data output time: %.3f sec\n", t_out);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && (!strcmp(argv[1], "--version") || !strcmp(argv[1], "-V"))) {
+        fprintf(stdout, "sigfish-amd %s\n", sfa_version());
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "dtw")) return dtw_main(argc - 1, argv + 1);
+    fprintf(argc >= 2 && (!strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) ? stdout : stderr,
+            "Usage: sigfish-amd <command> [options]\n\ncommand:\n         dtw           map raw signal reads to a reference with subsequence DTW on an MI355X\n\n");
+    return (argc >= 2 && (!strcmp(argv[1], "--help") || !strcmp(argv[1], "-h"))) ? 0 : 1;
+}

@@ -332,6 +332,7 @@ int resolve_profile(sfa_ctx *c) {
 extern "C" {
 
 const char *sfa_last_error(void) { return g_err.c_str(); }
+void sfa_set_error_(const char *msg) { g_err = msg ? msg : ""; }  // for the host-side units of this library
 const char *sfa_version(void) { return SFA_VERSION; }
 
 int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {

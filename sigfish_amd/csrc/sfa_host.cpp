@@ -11,6 +11,11 @@
 
 #include "../../include/sigfish_amd.h"
 #include "sfa_plan.hpp"
+#include "host/blow5.hpp"
+#include "host/events.hpp"
+#include "host/refio.hpp"
+
+extern "C" void sfa_set_error_(const char *msg);
 
 namespace {
 
@@ -141,5 +146,81 @@ int sfa_paf_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_i
     if (n < 0 || static_cast<size_t>(n) >= cap) return -1;
     return n;
 }
+
+
+int64_t sfa_detect_events(const int16_t *raw, int64_t n_raw, double digitisation, double offset, double range, int rna,
+                          sfa_event_t *out, int64_t cap) {
+    if (!raw || n_raw < 0 || (cap > 0 && !out)) return SFA_EINVAL;
+    std::vector<float> pa(static_cast<size_t>(n_raw));
+    sfa::raw_to_picoamps(raw, n_raw, digitisation, offset, range, pa.data());
+    const std::vector<sfa_event_t> ev = sfa::detect_events(pa.data(), n_raw, rna != 0);
+    const int64_t n = static_cast<int64_t>(ev.size());
+    if (n > 0 && cap > 0) memcpy(out, ev.data(), sizeof(sfa_event_t) * static_cast<size_t>(n < cap ? n : cap));
+    return n;
+}
+
+int sfa_select_query(sfa_event_t *events, int64_t n_events, const int16_t *raw, int64_t n_raw, double digitisation,
+                     double offset, double range, int32_t prefix_size, int32_t query_size, uint32_t flag, int pore,
+                     int64_t *qstart, int64_t *qend) {
+    if (!events || n_events <= 0 || !qstart || !qend) return 0;
+    std::vector<sfa_event_t> ev(events, events + n_events);
+    std::vector<float> pa;
+    if (prefix_size < 0 && raw && n_raw > 0) {
+        pa.resize(static_cast<size_t>(n_raw));
+        sfa::raw_to_picoamps(raw, n_raw, digitisation, offset, range, pa.data());
+    }
+    int status = 0;
+    const bool keep = sfa::select_and_normalise(ev, raw, n_raw, pa.data(), prefix_size, query_size, flag, pore, qstart, qend, &status);
+    memcpy(events, ev.data(), sizeof(sfa_event_t) * static_cast<size_t>(n_events));
+    return keep ? 1 : 0;
+}
+
+int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k) {
+    if (!path || !levels || !k) return SFA_EINVAL;
+    std::vector<float> lv;
+    std::string err;
+    if (!sfa::read_kmer_model(path, &lv, k, &err)) {
+        sfa_set_error_(err.c_str());
+        return SFA_EINVAL;
+    }
+    memcpy(levels, lv.data(), sizeof(float) * lv.size());
+    return SFA_OK;
+}
+
+struct sfa_blow5 {
+    sfa::Blow5Reader reader;
+    sfa::Blow5Record rec;
+};
+
+sfa_blow5_t *sfa_blow5_open(const char *path) {
+    sfa_blow5 *f = new sfa_blow5();
+    if (!path || !f->reader.open(path)) {
+        sfa_set_error_(path ? f->reader.error().c_str() : "null path");
+        delete f;
+        return nullptr;
+    }
+    return f;
+}
+
+const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key) { return (f && key) ? f->reader.attr(key) : nullptr; }
+
+int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const int16_t **raw, int64_t *n_raw) {
+    if (!f) return SFA_EINVAL;
+    const int rc = f->reader.next(&f->rec);
+    if (rc < 0) sfa_set_error_(f->reader.error().c_str());
+    if (rc <= 0) return rc;
+    if (read_id) *read_id = f->rec.read_id.c_str();
+    if (meta) {
+        meta[0] = f->rec.digitisation;
+        meta[1] = f->rec.offset;
+        meta[2] = f->rec.range;
+        meta[3] = f->rec.sampling_rate;
+    }
+    if (raw) *raw = f->rec.raw.data();
+    if (n_raw) *n_raw = static_cast<int64_t>(f->rec.raw.size());
+    return 1;
+}
+
+void sfa_blow5_close(sfa_blow5_t *f) { delete f; }
 
 }  // extern "C"

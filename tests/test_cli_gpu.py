@@ -1,0 +1,58 @@
+"""End to end: the `sigfish-amd dtw` command line (own BLOW5/FASTA/model readers, event detection, query window,
+GPU alignment through the C-ABI, PAF writer) must print exactly what the compiled reference printed for the
+same files and flags (tests/golden/cases/*.out) -- "PAF identical to CPU on test/test.sh"."""
+import itertools
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, ROOT, case_names, load_case
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "sigfish_amd", "bin", "sigfish-amd")
+
+
+@pytest.fixture(scope="module")
+def models(tmp_path_factory):
+    d = tmp_path_factory.mktemp("models")
+    out = {}
+    for k in (5, 6):
+        lv = np.fromfile(os.path.join(GOLD, "models", f"syn{k}.f32"), np.float32)
+        p = d / f"syn{k}.model"
+        with open(p, "w") as f:
+            f.write(f"#k\t{k}\nkmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+            for kmer, v in zip(itertools.product("ACGT", repeat=k), lv):
+                f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
+        out[k] = str(p)
+    return out
+
+
+@pytest.mark.parametrize("name", [n for n in case_names() if "sam" not in n])
+def test_cli_matches_reference_output(name, models):
+    assert os.path.exists(BIN), "build with `make -C sigfish_amd/csrc`"
+    c = load_case(name)
+    args = [str(a) for a in c["args"]]
+    cmd = [BIN, "dtw", "--kmer-model", models[c["k"]], "--verbose", "0", *args, c["fasta"], c["blow5"]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+
+
+def test_cli_small_batches_keep_order(models):
+    """-K 2 forces several batches; output order and content must not change."""
+    c = load_case("rna_default")
+    cmd = [BIN, "dtw", "--kmer-model", models[5], "--verbose", "0", "-K", "3", "--rna", c["fasta"], c["blow5"]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+
+
+def test_cli_errors_like_reference(models):
+    c = load_case("dna_default")
+    for extra, msg in ((["--dtw-std"], "only available for RNA"), (["-p", "-1"], "auto query start")):
+        r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], *extra, c["fasta"], c["blow5"]], capture_output=True)
+        assert r.returncode != 0 and msg in r.stderr.decode()
+    r = subprocess.run([BIN, "dtw", c["fasta"], c["blow5"]], capture_output=True)
+    assert r.returncode != 0 and "--kmer-model" in r.stderr.decode()

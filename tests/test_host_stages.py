@@ -1,0 +1,72 @@
+"""Host pre-DP stages of the product (BLOW5 reader, event detection, query window + normalisation, k-mer model
+reader) against what the COMPILED REFERENCE produced for the same fixture files (tests/golden/cases/*.npz).
+CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import sigfish_amd as S
+from tests.util import GOLD, case_names, load_case
+
+
+def _pipeline(c):
+    rna = bool(c["flag"] & S.RNA)
+    f = S.Blow5File(c["blow5"])
+    out = []
+    for rid, meta, raw in f:
+        ev = S.detect_events(raw, meta, rna)
+        keep, qs, qe = (False, 0, 0)
+        if len(ev):
+            keep, qs, qe = S.select_query(ev, raw, meta, c["prefix_size"], c["query_size"], c["flag"], 0)
+        out.append((rid, len(raw), ev, keep, qs, qe))
+    return out
+
+
+def test_blow5_header_attrs():
+    f = S.Blow5File(os.path.join(GOLD, "data", "sp1_dna.blow5"))
+    assert f.attr("experiment_type") == "genomic_dna" and f.attr("sequencing_kit") == "sqk-lsk109"
+    assert f.attr("no_such_attr") is None
+    g = S.Blow5File(os.path.join(GOLD, "data", "sequin_rna.blow5"))
+    assert g.attr("experiment_type") == "rna"
+    with pytest.raises(S.SfaError):
+        S.Blow5File(os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"))
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_events_and_query_match_reference(name):
+    c = load_case(name)
+    got = _pipeline(c)
+    assert [g[0] for g in got] == [str(x) for x in c["read_ids"]]
+    assert [g[1] for g in got] == list(c["len_raw"])
+    assert [len(g[2]) for g in got] == list(c["n_events"])
+    vi = 0
+    for i, (rid, nraw, ev, keep, qs, qe) in enumerate(got):
+        assert keep == bool(c["read_valid"][i])
+        if not keep:
+            continue
+        assert (qs, qe) == (int(c["qstart"][i]), int(c["qend"][i])), rid
+        q = ev["mean"][qs:qe]
+        want = c["queries"][c["q_off"][vi]:c["q_off"][vi + 1]]
+        assert np.array_equal(q.view(np.uint32), want.view(np.uint32)), rid   # bit-identical query events
+        assert int(ev["start"][qs]) == int(c["ev_start_first"][vi])
+        assert int(ev["start"][qe - 1]) == int(c["ev_start_last"][vi])
+        assert ev["length"][qe - 1] == c["ev_len_last"][vi]
+        vi += 1
+
+
+def test_kmer_model_text_roundtrip(tmp_path):
+    import itertools
+    for k in (5, 6):
+        lv = np.fromfile(os.path.join(GOLD, "models", f"syn{k}.f32"), np.float32)
+        p = tmp_path / f"syn{k}.model"
+        with open(p, "w") as f:
+            f.write(f"#k\t{k}\nkmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+            for kmer, v in zip(itertools.product("ACGT", repeat=k), lv):
+                f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
+        got, kk = S.read_kmer_model(p)
+        assert kk == k and np.array_equal(got.view(np.uint32), lv.view(np.uint32))
+    bad = tmp_path / "short.model"
+    bad.write_text("#k\t5\nAAAAA\t1.0\t1.0\n")
+    with pytest.raises(S.SfaError, match="prematurely"):
+        S.read_kmer_model(bad)
