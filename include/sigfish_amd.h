@@ -180,6 +180,15 @@ int sfa_select_query(sfa_event_t *events, int64_t n_events, const int16_t *raw, 
                      double offset, double range, int32_t prefix_size, int32_t query_size, uint32_t flag, int pore,
                      int64_t *qstart, int64_t *qend);
 
+/* One SAM line for a result row (sam_str, src/sigfish.c:770-794, with path_to_map 530-571 and the "ss" string of
+ * r2qevent_map_to_ss 663-768).  The warp path of the winner is rebuilt on the host from the band between its
+ * start and end columns.  events/qstart/qend: the read's event table and query window as for sfa_align_events
+ * (means z-normalised); ref_array: the winner's (contig,strand) array -- forward[rid] for '+', reverse[rid] for
+ * '-' -- of ref_len floats; ref_st_offset as given to sfa_init.  Returns bytes written or <0. */
+int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname,
+                const sfa_event_t *events, int64_t qstart, int64_t qend, const float *ref_array, int32_t ref_len,
+                int32_t ref_st_offset, uint32_t flag);
+
 /* read_model (src/model.c:38-131): text k-mer model -> level_mean[4^k] (levels must hold 262144 floats). */
 int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k);
 

@@ -41,7 +41,7 @@ class SfaEvent(C.Structure):
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
-           "sfa_znormalise", "sfa_paf_row", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
+           "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close"]
 
 _lib = None
@@ -79,6 +79,8 @@ def load():
     L.sfa_paf_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(SfaResult), C.c_char_p, C.c_char_p, C.c_uint64,
                               C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
     i16p = C.POINTER(C.c_int16)
+    L.sfa_sam_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(SfaResult), C.c_char_p, C.c_char_p, C.POINTER(SfaEvent),
+                              C.c_int64, C.c_int64, f32p, C.c_int32, C.c_int32, C.c_uint32]
     L.sfa_detect_events.argtypes = [i16p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(SfaEvent),
                                     C.c_int64]
     L.sfa_detect_events.restype = C.c_int64

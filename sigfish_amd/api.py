@@ -305,3 +305,17 @@ def read_kmer_model(path):
     _check(_lib.load().sfa_read_kmer_model(str(path).encode(), lv.ctypes.data_as(_lib.f32p), C.byref(k)),
            "sfa_read_kmer_model")
     return lv[:4 ** k.value].copy(), k.value
+
+
+def sam_row(res, read_id, rname, events, qstart, qend, ref_array, ref_st_offset, flag):
+    """sam_str (src/sigfish.c:770-794) for one result row; `events` normalised as for align_events."""
+    r = _lib.SfaResult(int(res["rid"]), int(res["pos_st"]), int(res["pos_end"]), float(res["score"]),
+                       float(res["score2"]), int(res["strand"]), int(res["mapq"]), int(res["valid"]), 0)
+    y = _f32(ref_array)
+    buf = C.create_string_buffer(1 << 22)
+    n = _lib.load().sfa_sam_row(buf, len(buf), C.byref(r), str(read_id).encode(), str(rname).encode(),
+                                C.cast(events.ctypes.data, C.POINTER(_lib.SfaEvent)), int(qstart), int(qend),
+                                y.ctypes.data_as(_lib.f32p), len(y), int(ref_st_offset), int(flag))
+    if n < 0:
+        raise SfaError(f"sfa_sam_row failed ({n})")
+    return buf.raw[:n].decode()

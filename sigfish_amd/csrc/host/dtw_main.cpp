@@ -185,7 +185,6 @@ int dtw_main(int argc, char **argv) {
         if (o.flag & F_INV) die("Inversion is not compatible with auto query start detection.");
         if (o.flag & F_END) die("Mapping from query end is not compatible with auto query start detection.");
     }
-    if (o.flag & F_SAM) die("--sam is not available in this build yet (PAF only)");
 
     // ---- init_core(), src/sigfish.c:81-207 ----
     sfa::Blow5Reader reader;
@@ -233,6 +232,11 @@ int dtw_main(int argc, char **argv) {
     sfa_ref_t sref{nref, ref_len.data(), ref_off.data(), fp.data(), rna ? nullptr : rp.data()};
     sfa_ctx_t *ctx = nullptr;
     if (sfa_init(&ctx, &sref, o.flag, o.device) != SFA_OK) die(std::string("accelerator init failed: ") + sfa_last_error());
+
+    if (o.flag & F_SAM) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
+        for (int32_t i = 0; i < nref; ++i) fprintf(stdout, "@SQ\tSN:%s\tLN:%ld\n", contigs[i].name.c_str(), static_cast<long>(ref_len[i]));
+        fprintf(stdout, "@PG\tID:sigfish\tPN:sigfish\tVN:0.2.0\n");
+    }
 
     // ---- batch loop, src/dtw_main.c:299-326 ----
     double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
@@ -302,6 +306,26 @@ int dtw_main(int argc, char **argv) {
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) processed\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
         a = realtime();
+        if (o.flag & F_SAM) {
+            // the warp path of every winner is rebuilt on the host from its band (sam.hpp), one read per task
+            std::vector<std::string> sam(n);
+            parallel_for(n, o.threads, [&](int64_t i) {
+                const Read &r = batch[i];
+                const sfa_result_t &row = rows[i];
+                if (!r.keep || !row.valid || row.rid < 0) return;
+                const float *y = row.strand == '+' ? fwd[row.rid].data() : rev[row.rid].data();
+                std::string buf(1 << 16, '\0');
+                int len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
+                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
+                if (len == SFA_ERANGE) {  // very long ss strings (full-reference alignments)
+                    buf.assign(1 << 22, '\0');
+                    len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
+                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
+                }
+                if (len > 0) sam[i].assign(buf.data(), len);
+            });
+            for (int32_t i = 0; i < n; ++i) fwrite(sam[i].data(), 1, sam[i].size(), stdout);
+        } else
         for (int32_t i = 0; i < n; ++i) {  // output_db + aln_to_str, src/sigfish.c:796-826,1051-1086
             const Read &r = batch[i];
             if (!r.keep || !rows[i].valid || rows[i].rid < 0) continue;

@@ -14,6 +14,7 @@
 #include "host/blow5.hpp"
 #include "host/events.hpp"
 #include "host/refio.hpp"
+#include "host/sam.hpp"
 
 extern "C" void sfa_set_error_(const char *msg);
 
@@ -173,6 +174,26 @@ int sfa_select_query(sfa_event_t *events, int64_t n_events, const int16_t *raw, 
     const bool keep = sfa::select_and_normalise(ev, raw, n_raw, pa.data(), prefix_size, query_size, flag, pore, qstart, qend, &status);
     memcpy(events, ev.data(), sizeof(sfa_event_t) * static_cast<size_t>(n_events));
     return keep ? 1 : 0;
+}
+
+int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname, const sfa_event_t *events,
+                int64_t qstart, int64_t qend, const float *ref_array, int32_t ref_len, int32_t ref_st_offset, uint32_t flag) {
+    if (!buf || !r || !read_id || !rname || !events || !ref_array || qend <= qstart || !r->valid || r->rid < 0) return SFA_EINVAL;
+    const bool rna = (flag & SFA_RNA) != 0;
+    const int32_t qlen = static_cast<int32_t>(qend - qstart);
+    std::vector<float> q(static_cast<size_t>(qlen));
+    const bool reversed = rna && !(flag & SFA_INV);  // src/sigfish.c:860-866
+    for (int32_t j = 0; j < qlen; ++j) q[reversed ? qlen - 1 - j : j] = events[qstart + j].mean;
+    // undo the strand flip and offset of src/sigfish.c:971-975 to get columns of the strand's own array
+    const bool plus = r->strand == '+';
+    const int32_t st = plus ? r->pos_st - ref_st_offset : ref_len - (r->pos_end - ref_st_offset);
+    const int32_t en = plus ? r->pos_end - ref_st_offset : ref_len - (r->pos_st - ref_st_offset);
+    const sfa::WarpPath path = sfa::band_traceback(q.data(), qlen, ref_array, ref_len, st, en, (flag & SFA_DTW) != 0);
+    if (path.px.empty()) return SFA_EINVAL;
+    const std::string line = sfa::sam_record(*r, path, read_id, rname, events, qstart, qend, rna);
+    if (line.size() + 1 > cap) return SFA_ERANGE;
+    memcpy(buf, line.c_str(), line.size() + 1);
+    return static_cast<int>(line.size());
 }
 
 int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k) {

@@ -29,7 +29,7 @@ def models(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("name", [n for n in case_names() if "sam" not in n])
+@pytest.mark.parametrize("name", case_names())
 def test_cli_matches_reference_output(name, models):
     assert os.path.exists(BIN), "build with `make -C sigfish_amd/csrc`"
     c = load_case(name)

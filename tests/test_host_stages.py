@@ -70,3 +70,25 @@ def test_kmer_model_text_roundtrip(tmp_path):
     bad.write_text("#k\t5\nAAAAA\t1.0\t1.0\n")
     with pytest.raises(S.SfaError, match="prematurely"):
         S.read_kmer_model(bad)
+
+
+@pytest.mark.parametrize("name", ["dna_sam", "rna_sam"])
+def test_sam_rows_from_reference_alignments(name):
+    """SAM writer + host-side warp-path recovery: fed with the reference's own aln_t rows, it must print the
+    reference's SAM records (path_to_map / ss string / si tag) byte for byte."""
+    c = load_case(name)
+    ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
+    rows = np.zeros(len(c["rid"]), S.RESULT_DTYPE)
+    for f in ("rid", "pos_st", "pos_end", "score", "score2", "strand", "mapq"):
+        rows[f] = c[f]
+    rows["valid"] = 1
+    want = [l + "\n" for l in c["out_text"].split("\n") if l and not l.startswith("@")]
+    got, vi = [], 0
+    for rid, nraw, ev, keep, qs, qe in _pipeline(c):
+        if not keep:
+            continue
+        r = rows[vi]
+        arr = ref.forward[int(r["rid"])] if r["strand"] == ord("+") else ref.reverse[int(r["rid"])]
+        got.append(S.sam_row(r, rid, ref.names[int(r["rid"])], ev, qs, qe, arr, int(ref.st_offset[int(r["rid"])]), c["flag"]))
+        vi += 1
+    assert got == want
