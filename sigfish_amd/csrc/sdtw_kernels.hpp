@@ -12,10 +12,11 @@
 // Mapping to the machine (MI355X-first, not a translation of the CPU loops):
 //   * one read occupies ONE DPP ROW (16 lanes) of a wave64; four reads ("a quad", equal query length) ride in
 //     a wave.  Lane g of a row owns R consecutive query rows (R = 4/8/16/32 -> queries up to 64/128/256/512
-//     events), kept in VGPRs together with their running cost.  No LDS, no barriers, no cost matrix.
+//     events), kept in VGPRs together with their running cost.  No barriers, no cost matrix.
 //   * the lanes of a row walk an anti-diagonal: at step t lane g is at reference column t-g, so the only
-//     cross-lane traffic per step is ONE `v_mov_b32_dpp row_shr:1` of the bottom cost: the neighbour's value
-//     from the previous step is this lane's "up", the one before its "diagonal".
+//     cross-lane traffic per step is ONE value per lane, the bottom cost handed to the next lane (through a
+//     wave-private LDS window, see Exchange): the neighbour's value from the previous step is this lane's "up",
+//     the one before its "diagonal".
 //   * +inf initial state makes not-yet-started columns (t-g < 0) and past-the-end columns harmless, so the inner
 //     loop carries no per-lane predication; reference arrays are padded in HBM so the per-lane 16-byte loads of
 //     four upcoming reference levels never leave the allocation (they hit L1/L2: every wave streams the same
@@ -91,18 +92,44 @@ struct DpArgs {
     int32_t trace_margin;  // pass 2 starts from the last checkpoint at least this many steps before the winner
 };
 
-__device__ __forceinline__ float dpp_row_shr1_zero(float v) {
-    // lane g receives lane g-1 of its 16-lane row; lane 0 of every row receives 0.0f (bound_ctrl)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_row_shr1_old(float old, float v) {
-    // same, but lane 0 of every row keeps `old`
-    return __int_as_float(
-        __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x111, 0xF, 0xF, false));
-}
-__device__ __forceinline__ int dpp_row_shr1_zero(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
-}
+// Neighbour exchange.  Lane g needs the bottom cost lane g-1 produced in the previous step.  On gfx950 a
+// `v_mov_b32_dpp row_shr:1` in this dependent position costs the SIMD ~40 issue cycles per step (measured,
+// tools/valu_ceiling.hip: 0.34 vs 0.45 VALU instructions per cycle per SIMD), so the value makes a round trip
+// through a wave-private LDS window instead: every lane stores its bottom value in word g+1 of its read's
+// 17-word window and loads word g; word 0 holds the boundary value for query row 0.  LDS operations of one
+// wave execute in order, the windows are private to the wave, hence no barrier; the LDS pipe is otherwise idle.
+constexpr int kXchWordsPerWave = kReadsPerWave * (kLanesPerRead + 1);  // 68
+
+struct Exchange {
+    float *wf;  // this lane's slot (bottom cost)
+    int *wi;    // this lane's slot (bottom start column), TRACK only
+    __device__ __forceinline__ void init(float *lds_f, int *lds_i, int wave_in_block, int slot, int g) {
+        wf = lds_f + wave_in_block * kXchWordsPerWave + slot * (kLanesPerRead + 1) + g + 1;
+        wi = lds_i + wave_in_block * kXchWordsPerWave + slot * (kLanesPerRead + 1) + g + 1;
+    }
+    // boundary seen by lane 0 (query row 0): 0 = free start of subsequence(); std_dtw() switches it to +inf after column 0
+    template <bool TRACK>
+    __device__ __forceinline__ void set_boundary(bool lane0, float vf) {
+        if (lane0) {
+            *((lds_vf *)wf - 1) = vf;
+            if (TRACK) *((lds_vi *)wi - 1) = 0;
+        }
+    }
+    // volatile: the neighbour's slot is written by ANOTHER lane, which the single-thread memory model cannot see;
+    // the explicit LDS address space keeps these as plain ds_write_b32 / ds_read_b32
+    typedef __attribute__((address_space(3))) volatile float lds_vf;
+    typedef __attribute__((address_space(3))) volatile int lds_vi;
+    __device__ __forceinline__ float shift(float bottom) {
+        lds_vf *w = (lds_vf *)wf;
+        *w = bottom;
+        return *(w - 1);
+    }
+    __device__ __forceinline__ int shift(int bottom) {
+        lds_vi *w = (lds_vi *)wi;
+        *w = bottom;
+        return *(w - 1);
+    }
+};
 
 // Per-lane state lives in R-wide register tuples.  A wave-uniform (SGPR) index into such a tuple lowers to
 // s_set_gpr_idx_on / v_mov_b32 / s_set_gpr_idx_off on gfx950: one VALU op to read "the register that holds the
@@ -161,16 +188,15 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
 //   t      step index (wave-uniform int in the fill, per-lane in the trace); lane 0's column is t
 template <int R, bool TRACK, bool STD, typename TT, typename CF, typename CI>
 __device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev, const float (&x)[R], const float yv, const TT t,
-                                        const bool lane0) {
-    // inputs from the lane above (query row g*R-1); lane 0 owns query row 0 and receives the boundary instead
-    float up;
-    if (!STD) {
-        up = dpp_row_shr1_zero(c[R - 1]);  // subsequence(): C[0][j] = d + 0  (free start)
-    } else {
-        up = dpp_row_shr1_old((t == 0) ? 0.0f : INFINITY, c[R - 1]);  // std_dtw(): C[0][0]=d, C[0][j]=d+C[0][j-1]
-    }
+                                        const bool lane0, Exchange &xc) {
+    // inputs from the lane above (query row g*R-1); lane 0 owns query row 0 and receives the boundary instead:
+    // subsequence(): C[0][j] = d + 0 (free start); std_dtw(): C[0][0] = d, then C[0][j] = d + C[0][j-1] (boundary +inf)
+    float up = xc.shift(static_cast<float>(c[R - 1]));
     int sup = 0;
-    if (TRACK) sup = dpp_row_shr1_zero(s[R - 1]);
+    if (TRACK) sup = xc.shift(static_cast<int>(s[R - 1]));
+    if (STD) {
+        if (t == 0) xc.template set_boundary<TRACK>(lane0, INFINITY);  // from column 1 on, row 0 only continues from its left neighbour
+    }
     float diag = dprev;
     int sdiag = sdprev;
     dprev = up;
@@ -180,7 +206,15 @@ __device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev,
     for (int r = 0; r < R; ++r) {
         const float left = c[r];
         const int sleft = s[r];
-        const float m = fminf(fminf(up, diag), left);  // v_min3_f32; no NaNs on this path
+        float m;
+        if (r == 0) {
+            // `up` and `diag` come out of LDS here; costs are non-negative floats, whose order is the order of their
+            // bit patterns, so an unsigned min3 gives the same value without the sNaN-quieting ops fminf would add
+            const unsigned mu = min(min(__float_as_uint(up), __float_as_uint(diag)), __float_as_uint(left));
+            m = __uint_as_float(mu);
+        } else {
+            m = fminf(fminf(up, diag), left);  // v_min3_f32; no NaNs on this path
+        }
         const float cn = fabsf(x[r] - yv) + m;
         int sn = 0;
         if (TRACK) {
@@ -219,7 +253,7 @@ __device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, 
 __device__ __forceinline__ int sweep_begin(int lq) { return lq - ((lq + kStepsPerLoad - 1) & ~(kStepsPerLoad - 1)); }
 
 template <int R, bool TRACK, bool STD>
-__device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local) {
+__device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
     const int quad_local = task_local - chunk * cd.n_quads;
     const int quad = cd.quad_base + quad_local;
@@ -236,6 +270,8 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
 
     float x[R];
     load_query_rows<R>(x, a, read, qlen, g);
+    Exchange xc;
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g);
 
     Top2<TRACK> top;
     top.init();
@@ -259,6 +295,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         }
         float dprev = INFINITY;
         int sdprev = 0;
+        xc.template set_boundary<TRACK>(lane0, 0.0f);
         float wmin = INFINITY;  // running minimum of the current last-row window
         int wpos = -1, wst = -1;
         int wleft = qlen;
@@ -307,7 +344,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
             }
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u)
-                dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0);
+                dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
             ycur = ynext;
         }
         // ---- main: every step yields one last-row cell ----
@@ -329,8 +366,12 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
                 }
 #pragma unroll
                 for (int u = 0; u < kStepsPerLoad; ++u) {
-                    dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0);
+                    dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+#ifdef SFA_EXP_NOPICK
+                    if (!STD) last_row(cv[R - 1], TRACK ? sv[R - 1] : 0);
+#else
                     if (!STD) last_row(cv[rq], TRACK ? sv[rq] : 0);
+#endif
                 }
                 ycur = ynext;
             }
@@ -350,7 +391,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad - 1; ++u) {
                 if (u < rem) {
-                    dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0);
+                    dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
                     if (!STD) last_row(pick_chain<R>(c, rq), TRACK ? pick_chain<R>(s, rq) : 0);
                 }
             }
@@ -383,18 +424,20 @@ __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES :
     while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
     const ClassDesc cd = a.cls[ci];
     const int tl = task - cd.task_base;
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
     switch (cd.R) {
         case 32:
-            if constexpr (MAXR >= 32) fill_body<32, TRACK, STD>(a, cd, tl);
+            if constexpr (MAXR >= 32) fill_body<32, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
         case 16:
-            if constexpr (MAXR >= 16) fill_body<16, TRACK, STD>(a, cd, tl);
+            if constexpr (MAXR >= 16) fill_body<16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
         case 8:
-            if constexpr (MAXR >= 8) fill_body<8, TRACK, STD>(a, cd, tl);
+            if constexpr (MAXR >= 8) fill_body<8, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
         default:
-            fill_body<4, TRACK, STD>(a, cd, tl);
+            fill_body<4, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
     }
 }
@@ -406,7 +449,8 @@ __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES :
 struct ResultRow;  // below
 
 template <int R, bool STD>
-__device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st) {
+__device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st, float *lds_f,
+                                           int *lds_i) {
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
     const int g = lane & (kLanesPerRead - 1);
@@ -420,6 +464,8 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
 
     float x[R];
     load_query_rows<R>(x, a, read, qlen, g);
+    Exchange xc;
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g);
 
     int job = (read >= 0) ? a.w_job[read] : -1;
     const int end = (read >= 0) ? a.w_end[read] : 0;
@@ -467,6 +513,8 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
             dprev = INFINITY;
             sdprev = 0;
         }
+        // std_dtw(): a row that restarts at or before column 0 begins with the free boundary, later ones with +inf
+        xc.template set_boundary<true>(lane0, (STD && tb > 0) ? INFINITY : 0.0f);
         const int len = done ? 0 : (t_end - tb + 1);
         int maxlen = __builtin_amdgcn_readlane(len, 0);
         maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
@@ -482,7 +530,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u) {
                 const int t = tb + tau0 + u;
-                dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t, lane0);
+                dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t, lane0, xc);
                 const int sl = s[rq];
                 cap = (t == t_end) ? sl : cap;
             }
@@ -537,18 +585,20 @@ __global__ void __launch_bounds__(256) sdtw_trace_kernel(const DpArgs a, int32_t
     while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
     const ClassDesc cd = a.cls[ci];
     const int tl = task - cd.task_base;
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[4 * kXchWordsPerWave];
     switch (cd.R) {
         case 32:
-            if constexpr (MAXR >= 32) trace_body<32, STD>(a, cd, tl, out_st);
+            if constexpr (MAXR >= 32) trace_body<32, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
         case 16:
-            if constexpr (MAXR >= 16) trace_body<16, STD>(a, cd, tl, out_st);
+            if constexpr (MAXR >= 16) trace_body<16, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
         case 8:
-            if constexpr (MAXR >= 8) trace_body<8, STD>(a, cd, tl, out_st);
+            if constexpr (MAXR >= 8) trace_body<8, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
         default:
-            trace_body<4, STD>(a, cd, tl, out_st);
+            trace_body<4, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
     }
 }
