@@ -252,6 +252,126 @@ __device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, 
 // +inf padding in front of every reference array, which keeps those cells at +inf.
 __device__ __forceinline__ int sweep_begin(int lq) { return lq - ((lq + kStepsPerLoad - 1) & ~(kStepsPerLoad - 1)); }
 
+// Checkpoint record: R cost planes + dprev plane + one plane holding the number of steps elapsed since t_begin
+// when the snapshot was taken (blocks are not aligned to T, so the k-th snapshot sits at the first block boundary
+// with e >= k*T; the trace kernel resumes from exactly that step).
+template <int R>
+__device__ __forceinline__ constexpr int ck_planes() { return R + 2; }
+
+// One (contig,strand) sweep of a quad.  RQ >= 0: the register holding the last query row is a compile-time
+// constant (hot specialisation); RQ < 0: it is the wave-uniform value rq (indexed v_mov).
+template <int R, bool TRACK, bool STD, int RQ>
+__device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
+                                          const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<TRACK> &top,
+                                          const int job, float *ckp, const int T) {
+    typename Vec<float, R>::type cv;
+    typename Vec<int, R>::type sv;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        cv[r] = INFINITY;
+        sv[r] = 0;
+    }
+    float dprev = INFINITY;
+    int sdprev = 0;
+    xc.template set_boundary<TRACK>(lane0, 0.0f);
+
+    int e = 0;               // steps executed so far; the next step is t = t_begin + e
+    int ck_next = T ? T : 0x7fffffff;
+    const int ck_last = T ? ((rlen > 4 ? rlen - 4 : 0) >> a.ck_shift) << a.ck_shift : 0;  // last k*T that is stored
+    auto maybe_checkpoint = [&]() {  // at a block boundary: snapshot the state BEFORE step t_begin + e
+        if (!TRACK && T) {
+            if (e >= ck_next && ck_next <= ck_last) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
+                ckp[R * 64] = dprev;
+                ckp[(R + 1) * 64] = __int_as_float(e);
+                ckp += ck_planes<R>() * 64;
+                ck_next += T;
+            }
+        }
+    };
+
+    float4u ycur = *reinterpret_cast<const float4u *>(yp);
+    // ---- prologue: the last query row has not reached column 0 yet (e_main = roundup4(lq) steps) ----
+    const int e_main = lq - t_begin;
+    for (; e < e_main; e += kStepsPerLoad) {
+        const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+        maybe_checkpoint();
+#pragma unroll
+        for (int u = 0; u < kStepsPerLoad; ++u)
+            dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+        ycur = ynext;
+    }
+    // ---- main: one last-row cell per step, consumed window by window (src/sigfish.c:891-901).  Blocks of four
+    // steps start wherever the previous window ended (the 16-byte reference loads need no alignment), so the
+    // steady-state block carries no window-end test at all. ----
+    int jqv = 0;  // last-row column of the next step
+    for (int col = 0; col < rlen;) {
+        const int wl = STD ? rlen : min(qlen, rlen - col);  // std_dtw has a single candidate: one "window"
+        const int nb = wl >> 2, rm = wl & 3;
+        float wmin = INFINITY;
+        int wpos = -1, wst = -1;
+        auto track = [&]() {  // first strict minimum of the window
+            const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
+            const bool lt = cl < wmin;
+            wmin = lt ? cl : wmin;
+            wpos = lt ? jqv : wpos;
+            if (TRACK) {
+                const int sl = (RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq]);
+                wst = lt ? sl : wst;
+            }
+            jqv += 1;
+        };
+        for (int b = 0; b < nb; ++b) {
+            const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+            maybe_checkpoint();
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad; ++u) {
+                dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+                if (!STD) track();
+            }
+            e += kStepsPerLoad;
+            ycur = ynext;
+        }
+        if (rm) {  // ragged end of the window: 1..3 steps, then the next window's loads start right behind them
+            const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + rm);
+            maybe_checkpoint();
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad - 1; ++u) {
+                if (u < rm) {
+                    dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+                    if (!STD) track();
+                }
+            }
+            e += rm;
+            ycur = ynext;
+        }
+        if (!STD) {
+            top.offer(wmin, wpos, wst, job);
+        } else {  // std_dtw: the single candidate C[n-1][m-1]
+            const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
+            const int sl = TRACK ? ((RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq])) : 0;
+            top.offer(cl, rlen - 1, sl, job);
+        }
+        col += wl;
+    }
+}
+
+// Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill.
+template <int R, bool TRACK, bool STD, int I = 0>
+__device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
+                                               const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T) {
+    if constexpr (TRACK || STD) {
+        sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+    } else {
+        if (rq == I) {
+            sweep_job<R, TRACK, STD, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+        } else if constexpr (I + 1 < R) {
+            sweep_dispatch<R, TRACK, STD, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+        }
+    }
+}
+
 template <int R, bool TRACK, bool STD>
 __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
@@ -276,131 +396,16 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     Top2<TRACK> top;
     top.init();
 
-    const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
-    const int64_t ck_total = a.ck_shift ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
+    const int T = (!TRACK && a.ck_shift) ? (1 << a.ck_shift) : 0;
+    const int64_t ck_total = T ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
 
     const int jb = a.chunk_begin[chunk], je = a.chunk_begin[chunk + 1];
     for (int job = jb; job < je; ++job) {
         const int rlen = a.job_len[job];
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
-
-        // State between phases lives in plain registers; the steady-state loop works on register TUPLES so that the
-        // last-row pick is a single indexed v_mov (see Vec).
-        float c[R];
-        int s[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            c[r] = INFINITY;
-            s[r] = 0;
-        }
-        float dprev = INFINITY;
-        int sdprev = 0;
-        xc.template set_boundary<TRACK>(lane0, 0.0f);
-        float wmin = INFINITY;  // running minimum of the current last-row window
-        int wpos = -1, wst = -1;
-        int wleft = qlen;
-        int jqv = 0;  // last-row column of the current step, kept in a VGPR for the selects
         float *ckp = nullptr;
-        if (!TRACK && T)
-            ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * ((R + 1) * 64) + lane;
-
-        // e = steps elapsed since t_begin (multiple of 4); step index t = t_begin + e + u
-        const int e_main = lq - t_begin;          // first block whose steps touch last-row column 0
-        const int e_tail = e_main + (rlen & ~(kStepsPerLoad - 1));  // first block with a ragged end
-        const int rem = rlen & (kStepsPerLoad - 1);
-        float4u ycur = *reinterpret_cast<const float4u *>(yp);
-
-        // windowed first-strict-minimum scan of src/sigfish.c:891-901 for one last-row cell (cl, sl)
-        auto last_row = [&](const float cl, const int sl) {
-            const bool lt = cl < wmin;
-            wmin = lt ? cl : wmin;
-            wpos = lt ? jqv : wpos;
-            if (TRACK) wst = lt ? sl : wst;
-            jqv += 1;
-#ifdef SFA_EXP_NOWINDOW
-            if (false) {
-#else
-            if (__builtin_expect(--wleft == 0, 0)) {
-#endif
-                top.offer(wmin, wpos, wst, job);
-                wmin = INFINITY;
-                wpos = -1;
-                wst = -1;
-                wleft = qlen;
-            }
-        };
-        // checkpoint k = el/T: the state BEFORE step t_begin+el, stored for 1 <= k <= (rlen-1)/T
-        auto is_checkpoint = [&](int el) { return !TRACK && T && el != 0 && (el & (T - 1)) == 0 && el < rlen; };
-
-        int e = 0;
-        // ---- prologue: the last query row has not reached column 0 yet ----
-        for (; e < e_main; e += kStepsPerLoad) {
-            const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
-            if (is_checkpoint(e)) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) ckp[r * 64] = c[r];
-                ckp[R * 64] = dprev;
-                ckp += (R + 1) * 64;
-            }
-#pragma unroll
-            for (int u = 0; u < kStepsPerLoad; ++u)
-                dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
-            ycur = ynext;
-        }
-        // ---- main: every step yields one last-row cell ----
-        {
-            typename Vec<float, R>::type cv;
-            typename Vec<int, R>::type sv;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                cv[r] = c[r];
-                sv[r] = s[r];
-            }
-            for (; e < e_tail; e += kStepsPerLoad) {
-                const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
-                if (is_checkpoint(e)) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
-                    ckp[R * 64] = dprev;
-                    ckp += (R + 1) * 64;
-                }
-#pragma unroll
-                for (int u = 0; u < kStepsPerLoad; ++u) {
-                    dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
-#ifdef SFA_EXP_NOPICK
-                    if (!STD) last_row(cv[R - 1], TRACK ? sv[R - 1] : 0);
-#else
-                    if (!STD) last_row(cv[rq], TRACK ? sv[rq] : 0);
-#endif
-                }
-                ycur = ynext;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                c[r] = cv[r];
-                s[r] = sv[r];
-            }
-        }
-        // ---- tail: rlen % 4 remaining last-row columns ----
-        if (rem) {
-            if (is_checkpoint(e)) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) ckp[r * 64] = c[r];
-                ckp[R * 64] = dprev;
-            }
-#pragma unroll
-            for (int u = 0; u < kStepsPerLoad - 1; ++u) {
-                if (u < rem) {
-                    dp_step<R, TRACK, STD, int>(c, s, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
-                    if (!STD) last_row(pick_chain<R>(c, rq), TRACK ? pick_chain<R>(s, rq) : 0);
-                }
-            }
-        }
-        if (!STD) {
-            if (wleft != qlen) top.offer(wmin, wpos, wst, job);  // the last, shorter window
-        } else {
-            top.offer(pick_chain<R>(c, rq), rlen - 1, TRACK ? pick_chain<R>(s, rq) : 0, job);  // std_dtw: C[n-1][m-1]
-        }
+        if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
+        sweep_dispatch<R, TRACK, STD>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
     }
 
     if (g == lq && read >= 0) {
@@ -478,10 +483,11 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
 
     const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
     const int64_t ck_total = a.ck_shift ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
-    const int nck = T ? (rlen - 1) >> a.ck_shift : 0;  // checkpoints stored for this job
+    const int nck = T ? (rlen > 4 ? rlen - 4 : 0) >> a.ck_shift : 0;  // checkpoints stored for this job
     int k = 0;
     if (T) {
-        const int from = t_end - a.trace_margin - t_begin;  // steps elapsed since t_begin
+        // snapshot k sits at most 3 steps after k*T, and it must not lie behind the winning cell
+        const int from = t_end - a.trace_margin - t_begin - 3;  // steps elapsed since t_begin
         k = from > 0 ? (from >> a.ck_shift) : 0;
         k = k < nck ? k : nck;
     }
@@ -489,14 +495,14 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     int result = -1;
 
     for (int attempt = 0; attempt < 40; ++attempt) {  // bounded: k reaches 0 after <= 32 halvings
-        const int tb = t_begin + (k << a.ck_shift);   // first step to execute
+        int tb = t_begin;  // first step to execute
         typename Vec<float, R>::type c;
         typename Vec<int, R>::type s;
         float dprev;
         int sdprev;
         if (k > 0) {  // restore the exact anti-diagonal state; provenance of these cells is unknown (-1)
             const float *ckp = a.ck + cd.ck_base +
-                               (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job] + (k - 1)) * ((R + 1) * 64) + lane;
+                               (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job] + (k - 1)) * (ck_planes<R>() * 64) + lane;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 c[r] = ckp[r * 64];
@@ -504,6 +510,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
             }
             dprev = ckp[R * 64];
             sdprev = -1;
+            tb = t_begin + __float_as_int(ckp[(R + 1) * 64]);  // the step this snapshot was taken before
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {

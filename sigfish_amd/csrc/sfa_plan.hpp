@@ -26,6 +26,10 @@ inline int rows_per_lane_for(int qlen) {
     return 0;
 }
 
+// checkpoints the fill stores for a job of rlen columns at interval 1<<shift: k*T <= rlen-4 (a block boundary at or
+// after k*T then always exists before the sweep ends); must match sweep_job() / trace_body() in sdtw_kernels.hpp
+inline int64_t ck_count(int32_t rlen, int shift) { return (rlen > 4 ? rlen - 4 : 0) >> shift; }
+
 struct PlanParams {
     int64_t n_sims = 1024;          // SIMDs on the device (CUs * 4)
     int64_t waves_per_simd = 6;     // occupancy to aim for when chunking
@@ -145,9 +149,9 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         }
         for (;; ++shift) {
             int64_t per_quad = 0;
-            for (int32_t j = 0; j < n_jobs; ++j) per_quad += (job_len[j] - 1) >> shift;
+            for (int32_t j = 0; j < n_jobs; ++j) per_quad += ck_count(job_len[j], shift);
             int64_t floats = 0;
-            for (const PlanClass &cl : p.classes) floats += per_quad * cl.n_quads * (cl.R + 1) * 64;
+            for (const PlanClass &cl : p.classes) floats += per_quad * cl.n_quads * (cl.R + 2) * 64;
             if (pp.ckpt_interval > 0 || floats * 4 <= pp.ckpt_budget_bytes || per_quad == 0 || shift >= 30) {
                 p.ck_shift = shift;
                 p.ck_floats = floats;
@@ -157,12 +161,12 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         int64_t base = 0, per_quad = 0;
         for (int32_t j = 0; j < n_jobs; ++j) {
             p.job_ck_off[j] = static_cast<int32_t>(per_quad);
-            per_quad += (job_len[j] - 1) >> p.ck_shift;
+            per_quad += ck_count(job_len[j], p.ck_shift);
         }
         p.job_ck_off[n_jobs] = static_cast<int32_t>(per_quad);
         for (PlanClass &cl : p.classes) {
             cl.ck_base = base;
-            base += per_quad * cl.n_quads * (cl.R + 1) * 64;
+            base += per_quad * cl.n_quads * (cl.R + 2) * 64;
         }
     }
     return 0;
