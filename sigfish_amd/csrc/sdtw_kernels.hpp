@@ -322,16 +322,27 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             }
             jqv += 1;
         };
-        for (int b = 0; b < nb; ++b) {
-            const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+        auto block = [&](const float4u &yv) {  // four steps on the levels in yv
             maybe_checkpoint();
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u) {
-                dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+                dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, yv.v[u], t_begin + e + u, lane0, xc);
                 if (!STD) track();
             }
             e += kStepsPerLoad;
-            ycur = ynext;
+        };
+        // two blocks per iteration so that the prefetched levels alternate between two register sets (no copies)
+        int b = 0;
+        for (; b + 1 < nb; b += 2) {
+            const float4u yb = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+            block(ycur);
+            ycur = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+            block(yb);
+        }
+        if (b < nb) {
+            const float4u yb = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+            block(ycur);
+            ycur = yb;
         }
         if (rm) {  // ragged end of the window: 1..3 steps, then the next window's loads start right behind them
             const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + rm);
