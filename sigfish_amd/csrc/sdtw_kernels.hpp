@@ -82,7 +82,8 @@ struct DpArgs {
     float *p_second;
     // winners per read (written by finalize, read by trace)
     int32_t *w_job;
-    int32_t *w_end;
+    int32_t *w_end;    // two-pass: first column of the winning WINDOW (the trace kernel finds the cell inside it)
+    float *w_score;    // two-pass: the winning score, to recognise that cell
     ClassDesc cls[kMaxClasses];
     int32_t n_cls;
     int32_t n_chunks;
@@ -90,29 +91,38 @@ struct DpArgs {
     int32_t rev_query;     // 1: query rows are the events reversed (RNA without --invert)
     int32_t ck_shift;      // checkpoint interval T = 1 << ck_shift steps; 0 = no checkpoints
     int32_t trace_margin;  // pass 2 starts from the last checkpoint at least this many steps before the winner
+    int32_t n_reads_total; // reads in the batch (trace output: start columns [n], end columns [n])
 };
 
 // Neighbour exchange.  Lane g needs the bottom cost lane g-1 produced in the previous step.  On gfx950 a
 // `v_mov_b32_dpp row_shr:1` in this dependent position costs the SIMD ~40 issue cycles per step (measured,
 // tools/valu_ceiling.hip: 0.34 vs 0.45 VALU instructions per cycle per SIMD), so the value makes a round trip
 // through a wave-private LDS window instead: every lane stores its bottom value in word g+1 of its read's
-// 17-word window and loads word g; word 0 holds the boundary value for query row 0.  LDS operations of one
+// window and loads word g; word 0 holds the boundary value for query row 0.  LDS operations of one
 // wave execute in order, the windows are private to the wave, hence no barrier; the LDS pipe is otherwise idle.
-constexpr int kXchWordsPerWave = kReadsPerWave * (kLanesPerRead + 1);  // 68
+// Bank-conflict-free layout (ds_*_b32: 32 banks, two 32-lane groups): read r's window is the 16 words
+// [16r, 16r+16): word 0 = boundary, lane g (< 15) stores to word g+1, every lane g loads word g.  Lane 15's value has
+// no reader; it goes to a private dummy word at 64+16r (banks 0/16, the two banks its group leaves free).
+constexpr int kXchWordsPerWave = 128;
 
 struct Exchange {
-    float *wf;  // this lane's slot (bottom cost)
-    int *wi;    // this lane's slot (bottom start column), TRACK only
+    float *wf, *rf;  // this lane's store / load slot (bottom cost)
+    int *wi, *ri;    // same for the bottom start column, TRACK only
     __device__ __forceinline__ void init(float *lds_f, int *lds_i, int wave_in_block, int slot, int g) {
-        wf = lds_f + wave_in_block * kXchWordsPerWave + slot * (kLanesPerRead + 1) + g + 1;
-        wi = lds_i + wave_in_block * kXchWordsPerWave + slot * (kLanesPerRead + 1) + g + 1;
+        const int base = wave_in_block * kXchWordsPerWave;
+        const int w = base + (g < kLanesPerRead - 1 ? slot * kLanesPerRead + g + 1 : 64 + 16 * slot);
+        const int r = base + slot * kLanesPerRead + g;
+        wf = lds_f + w;
+        rf = lds_f + r;
+        wi = lds_i + w;
+        ri = lds_i + r;
     }
     // boundary seen by lane 0 (query row 0): 0 = free start of subsequence(); std_dtw() switches it to +inf after column 0
     template <bool TRACK>
     __device__ __forceinline__ void set_boundary(bool lane0, float vf) {
         if (lane0) {
-            *((lds_vf *)wf - 1) = vf;
-            if (TRACK) *((lds_vi *)wi - 1) = 0;
+            *((lds_vf *)rf) = vf;
+            if (TRACK) *((lds_vi *)ri) = 0;
         }
     }
     // volatile: the neighbour's slot is written by ANOTHER lane, which the single-thread memory model cannot see;
@@ -120,14 +130,12 @@ struct Exchange {
     typedef __attribute__((address_space(3))) volatile float lds_vf;
     typedef __attribute__((address_space(3))) volatile int lds_vi;
     __device__ __forceinline__ float shift(float bottom) {
-        lds_vf *w = (lds_vf *)wf;
-        *w = bottom;
-        return *(w - 1);
+        *((lds_vf *)wf) = bottom;
+        return *((lds_vf *)rf);
     }
     __device__ __forceinline__ int shift(int bottom) {
-        lds_vi *w = (lds_vi *)wi;
-        *w = bottom;
-        return *(w - 1);
+        *((lds_vi *)wi) = bottom;
+        return *((lds_vi *)ri);
     }
 };
 
@@ -311,16 +319,21 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         const int nb = wl >> 2, rm = wl & 3;
         float wmin = INFINITY;
         int wpos = -1, wst = -1;
-        auto track = [&]() {  // first strict minimum of the window
+        // Cost-only pass: only the window MINIMUM is kept (one v_min per step).  Which column attains it first is
+        // settled in pass 2 for the single window that wins.  With tracking (single-pass mode) the first strict
+        // minimum, its column and its start column are selected here, as src/sigfish.c:892-899 does.
+        auto track = [&]() {
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
-            const bool lt = cl < wmin;
-            wmin = lt ? cl : wmin;
-            wpos = lt ? jqv : wpos;
-            if (TRACK) {
+            if (!TRACK) {
+                wmin = fminf(wmin, cl);
+            } else {
+                const bool lt = cl < wmin;
+                wmin = lt ? cl : wmin;
+                wpos = lt ? jqv : wpos;
                 const int sl = (RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq]);
                 wst = lt ? sl : wst;
+                jqv += 1;
             }
-            jqv += 1;
         };
         auto block = [&](const float4u &yv) {  // four steps on the levels in yv
             maybe_checkpoint();
@@ -358,7 +371,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             ycur = ynext;
         }
         if (!STD) {
-            top.offer(wmin, wpos, wst, job);
+            top.offer(wmin, TRACK ? wpos : col, wst, job);  // cost-only: the window is identified by its first column
         } else {  // std_dtw: the single candidate C[n-1][m-1]
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
             const int sl = TRACK ? ((RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq])) : 0;
@@ -484,26 +497,30 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g);
 
     int job = (read >= 0) ? a.w_job[read] : -1;
-    const int end = (read >= 0) ? a.w_end[read] : 0;
-    bool done = !(read >= 0 && job >= 0 && end >= 0);
+    const int ws = (read >= 0) ? a.w_end[read] : 0;  // first column of the winning window
+    const float best = (read >= 0) ? a.w_score[read] : 0.0f;
+    bool done = !(read >= 0 && job >= 0 && ws >= 0);
     job = done ? 0 : job;
     const int rlen = a.job_len[job];
-    const int t_begin = sweep_begin(lq);  // same time origin as the fill (checkpoint k = state before step t_begin+k*T)
+    const int wl = STD ? 1 : min(qlen, rlen - ws);  // std_dtw: the "window" is the last column alone
+    const int t_begin = sweep_begin(lq);             // same time origin as the fill
     const float *ybase = a.ref + a.job_off[job] - g;
-    const int t_end = end + lq;  // step at which lane lq evaluates the winning cell
+    const int t_first = ws + lq;            // step at which lane lq evaluates the first cell of the window
+    const int t_last = ws + wl - 1 + lq;    // ... and the last one
 
     const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
     const int64_t ck_total = a.ck_shift ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
     const int nck = T ? (rlen > 4 ? rlen - 4 : 0) >> a.ck_shift : 0;  // checkpoints stored for this job
     int k = 0;
     if (T) {
-        // snapshot k sits at most 3 steps after k*T, and it must not lie behind the winning cell
-        const int from = t_end - a.trace_margin - t_begin - 3;  // steps elapsed since t_begin
+        // snapshot k sits at most 3 steps after k*T, and it must not lie behind the window
+        const int from = t_first - a.trace_margin - t_begin - 3;  // steps elapsed since t_begin
         k = from > 0 ? (from >> a.ck_shift) : 0;
         k = k < nck ? k : nck;
     }
     int back = 1;
-    int result = -1;
+    int res_st = -1, res_end = -1;
+    const unsigned long long owner = __ballot(g == lq);  // the lanes that own a last query row
 
     for (int attempt = 0; attempt < 40; ++attempt) {  // bounded: k reaches 0 after <= 32 halvings
         int tb = t_begin;  // first step to execute
@@ -533,14 +550,16 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
         }
         // std_dtw(): a row that restarts at or before column 0 begins with the free boundary, later ones with +inf
         xc.template set_boundary<true>(lane0, (STD && tb > 0) ? INFINITY : 0.0f);
-        const int len = done ? 0 : (t_end - tb + 1);
+        const int len = done ? 0 : (t_last - tb + 1);
         int maxlen = __builtin_amdgcn_readlane(len, 0);
         maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
         maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
         maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
         if (maxlen <= 0) break;
 
-        int cap = -2;
+        // first cell of the window whose cost equals the winning score (= the first strict minimum the reference's
+        // scan selects, src/sigfish.c:892-899), and the start column carried into it
+        int cap_end = done ? 0 : -1, cap_st = -1;
         const int tlim = rlen + 16;  // keep the loads of rows that are already done inside the padded array
         for (int tau0 = 0; tau0 < maxlen; tau0 += kStepsPerLoad) {
             const int tbl = min(tb + tau0, tlim);
@@ -549,14 +568,20 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
             for (int u = 0; u < kStepsPerLoad; ++u) {
                 const int t = tb + tau0 + u;
                 dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t, lane0, xc);
+                const float cl = c[rq];
                 const int sl = s[rq];
-                cap = (t == t_end) ? sl : cap;
+                const bool hit = (cap_end < 0) && (t >= t_first) && (t <= t_last) && (cl == best);
+                cap_end = hit ? (t - lq) : cap_end;
+                cap_st = hit ? sl : cap_st;
             }
+            if ((__ballot(cap_end >= 0) & owner) == owner) break;  // every read of the quad has its cell
         }
-        const int capq = __shfl(cap, (lane & 48) + lq);  // the lane that owns the last query row
+        const int src = (lane & 48) + lq;  // the lane that owns the last query row of this read
+        const int q_end = __shfl(cap_end, src), q_st = __shfl(cap_st, src);
         if (!done) {
-            if (capq >= 0 || k == 0) {
-                result = capq;
+            if ((q_end >= 0 && q_st >= 0) || k == 0) {
+                res_end = q_end;
+                res_st = q_st;
                 done = true;
             } else {  // the path starts before this checkpoint: back off (1, 2, 4, ... checkpoints)
                 k = max(0, k - back);
@@ -565,7 +590,10 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
         }
         if (__all(done)) break;
     }
-    if (g == lq && read >= 0) out_st[read] = result;
+    if (g == lq && read >= 0) {
+        out_st[read] = res_st;
+        out_st[a.n_reads_total + read] = res_end;
+    }
 }
 
 // One result row per read, POD mirror of sfa_result_t (include/sigfish_amd.h).
@@ -589,7 +617,8 @@ struct FinalizeArgs {
     const int32_t *ref_st_offset;
     int32_t *w_job;  // two-pass: winners for the trace kernel
     int32_t *w_end;
-    const int32_t *t_st;  // two-pass, second finalize: start columns from the trace kernel
+    float *w_score;
+    const int32_t *t_st;  // two-pass, second finalize: start columns [n_reads] then end columns [n_reads] from the trace kernel
     ResultRow *out;       // [n_reads]
     int32_t n_reads, n_chunks;
     int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions
@@ -643,7 +672,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
         ResultRow r = a.out[i];
         if (r.rid < 0) return;
         const int st = a.t_st[i];
-        const int end = a.w_end[i];
+        const int end = a.t_st[a.n_reads + i];
         const int rl = a.ref_len[r.rid];
         const int off = a.ref_st_offset[r.rid];
         r.pos_st = ((r.strand == '+') ? st : rl - end) + off;  // src/sigfish.c:971-975
@@ -702,6 +731,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     if (a.mode == 1) {
         a.w_job[i] = wjob;
         a.w_end[i] = wend;
+        a.w_score[i] = r.score;
     }
     a.out[i] = r;
 }

@@ -121,7 +121,7 @@ struct sfa_ctx {
     DevBuf d_ref, d_job_off, d_job_len, d_job_contig, d_job_strand, d_ref_len, d_ref_off;
 
     // per-batch scratch
-    DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_tst, d_ck, d_out;
+    DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_wscore, d_tst, d_ck, d_out;
     PinBuf h_stage, h_out;
 
     sfa_profile_t prof{};
@@ -212,7 +212,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     const size_t n_part = static_cast<size_t>(std::max(n_quads, 1)) * n_chunks * 4;
     if ((rc = c->d_pbest.reserve(4 * n_part)) || (rc = c->d_pend.reserve(4 * n_part)) || (rc = c->d_pjob.reserve(4 * n_part)) ||
         (rc = c->d_psecond.reserve(4 * n_part)) || (rc = c->d_wjob.reserve(4 * (size_t)n)) || (rc = c->d_wend.reserve(4 * (size_t)n)) ||
-        (rc = c->d_tst.reserve(4 * (size_t)n)))
+        (rc = c->d_tst.reserve(8 * (size_t)n)) || (rc = c->d_wscore.reserve(4 * (size_t)n)))
         return rc;
     if (plan.single_pass && (rc = c->d_pst.reserve(4 * n_part))) return rc;
     if (!plan.single_pass && plan.ck_floats > 0 && (rc = c->d_ck.reserve(sizeof(float) * plan.ck_floats))) return rc;
@@ -240,6 +240,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.p_second = c->d_psecond.as<float>();
     da.w_job = c->d_wjob.as<int32_t>();
     da.w_end = c->d_wend.as<int32_t>();
+    da.w_score = c->d_wscore.as<float>();
+    da.n_reads_total = n;
     da.n_cls = static_cast<int32_t>(plan.classes.size());
     for (int i = 0; i < da.n_cls; ++i) {
         da.cls[i].R = plan.classes[i].R;
@@ -267,6 +269,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     fz.ref_st_offset = c->d_ref_off.as<int32_t>();
     fz.w_job = da.w_job;
     fz.w_end = da.w_end;
+    fz.w_score = da.w_score;
     fz.t_st = c->d_tst.as<int32_t>();
     fz.out = d_out;
     fz.n_reads = n;
@@ -419,7 +422,7 @@ void sfa_destroy(sfa_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_ref, &c->d_job_off, &c->d_job_len, &c->d_job_contig, &c->d_job_strand, &c->d_ref_len, &c->d_ref_off,
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
-                      &c->d_wend, &c->d_tst, &c->d_ck, &c->d_out})
+                      &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out})
         b->release();
     c->h_stage.release();
     c->h_out.release();
