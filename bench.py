@@ -145,7 +145,20 @@ def main():
     launches_per_step = max(launches // max(args.steps, 1), 1)
     achieved = alg_bytes / kern_s / 1e9
     cells_per_s_kernel = cells / kern_s
-    ops_per_cell = 3.375  # counted from the shipped R=16 fill ISA: 54 VALU per 16-cell step
+    ops_per_cell = 49 / 16  # counted from the shipped R=16 fill ISA: 49 VALU per 16-cell step
+    # HBM bytes per fill launch from the committed PMC passes of this build (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    # KB -> bytes; MI355X_MICROARCH.md section HBM).  Only quoted for the configuration that was profiled.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.csv")
+    if os.path.exists(pmc) and args.workload == "ncov_r9_dna_q250" and n == 100_000 and not args.opt:
+        vals = {}
+        for line in open(pmc).read().splitlines()[1:]:
+            kname, counter, _, mean, _ = line.rsplit(",", 4)
+            if "sdtw_fill_kernel" in kname:
+                vals[counter] = float(mean)
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+            traffic_src = "profiles/r01_v5_pmc_summary.csv (separate rocprofv3 --pmc passes of this build, same workload)"
     out = {
         "metric": "reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)",
         "value": round(value, 1),
@@ -164,7 +177,7 @@ def main():
         "dp_cells_per_s": round(cells * world * args.steps / elapsed, 1),
         "roofline": {
             "bound": "hbm", "kernel": "sdtw_fill_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_step": alg_bytes, "fill_launches_per_step": launches_per_step,
             "kernel_ms_per_step": round(kern_s * 1e3, 3),
             "trace_kernel_ms_per_step": round(sum(trace_ms) / max(len(trace_ms), 1), 3),
