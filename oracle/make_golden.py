@@ -140,6 +140,23 @@ def kernel_vectors():
     print(f"kernel vectors: {idx}")
 
 
+def eval_goldens():
+    """`sigfish eval truth.paf test.paf` (src/eval.c) printed by the reference build for the fixture PAFs."""
+    os.makedirs(os.path.join(GOLD, "eval"), exist_ok=True)
+    pairs = [("dna", "sp1_dna.minimap2.paf", "dna_default.out", []), ("rna", "sequin_rna.minimap2.paf", "rna_default.out", []),
+             ("rna_full_ref", "sequin_rna.minimap2.paf", "rna_full_ref.out", []),
+             ("rna_tid_only", "sequin_rna.minimap2.paf", "rna_default.out", ["--tid-only"]),
+             ("rna_nosec", "sequin_rna.minimap2.paf", "rna_q500_pauto.out", ["--secondary", "no"])]
+    for name, truth, test, extra in pairs:
+        cmd = [O.REF_DRIVER, "eval", *extra, os.path.join(GOLD, "data", truth), os.path.join(GOLD, "cases", test)]
+        r = subprocess.run(cmd, check=True, capture_output=True)
+        with open(os.path.join(GOLD, "eval", name + ".txt"), "wb") as f:
+            f.write(r.stdout)
+        with open(os.path.join(GOLD, "eval", name + ".args"), "w") as f:
+            f.write("\n".join([truth, test] + extra))
+    print("eval goldens:", len(pairs))
+
+
 def main():
     O.build()
     assert os.path.exists(O.REF_DRIVER), "oracle/_ref missing (needs /root/reference)"
@@ -155,6 +172,7 @@ def main():
     for c in CASES:
         run_case(*c)
     kernel_vectors()
+    eval_goldens()
 
 
 if __name__ == "__main__":

@@ -20,10 +20,12 @@ int8_t drna_detect(slow5_file_t *sp);
 refsynth_t *gen_ref(const char *genome, model_t *pore_model, uint32_t kmer_size, uint32_t flag, int32_t query_size);
 void free_ref(refsynth_t *ref);
 void free_db(db_t *db);
+int eval_main(int argc, char *argv[]); /* src/eval.c:380 */
 
 static void wr(FILE *f, const void *p, size_t n) { fwrite(p, 1, n, f); }
 
 int main(int argc, char **argv) {
+    if (argc >= 2 && strcmp(argv[1], "eval") == 0) return eval_main(argc - 1, argv + 1); /* the reference's `sigfish eval` */
     static struct option lo[] = {{"rna", 0, 0, 1},      {"dtw-std", 0, 0, 2}, {"invert", 0, 0, 3},
                                  {"full-ref", 0, 0, 4}, {"from-end", 0, 0, 5}, {"sam", 0, 0, 6},
                                  {"dump", 1, 0, 7},     {"model", 1, 0, 8},    {"kmer", 1, 0, 9},

@@ -356,13 +356,16 @@ int dtw_main(int argc, char **argv) {
     return 0;
 }
 
+int eval_main(int argc, char **argv);  // eval_main.cpp
+
 int main(int argc, char **argv) {
     if (argc >= 2 && (!strcmp(argv[1], "--version") || !strcmp(argv[1], "-V"))) {
         fprintf(stdout, "sigfish-amd %s\n", sfa_version());
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "dtw")) return dtw_main(argc - 1, argv + 1);
+    if (argc >= 2 && !strcmp(argv[1], "eval")) return eval_main(argc - 1, argv + 1);
     fprintf(argc >= 2 && (!strcmp(argv[1], "--help") || !strcmp(argv[1], "-h")) ? stdout : stderr,
-            "Usage: sigfish-amd <command> [options]\n\ncommand:\n         dtw           map raw signal reads to a reference with subsequence DTW on an MI355X\n\n");
+            "Usage: sigfish-amd <command> [options]\n\ncommand:\n         dtw           map raw signal reads to a reference with subsequence DTW on an MI355X\n         eval          compare a test PAF with a truth PAF (mapping accuracy)\n\n");
     return (argc >= 2 && (!strcmp(argv[1], "--help") || !strcmp(argv[1], "-h"))) ? 0 : 1;
 }

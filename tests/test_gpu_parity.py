@@ -139,6 +139,31 @@ def test_checkpoint_budget_picks_larger_interval():
     assert a.tobytes() == b.tobytes()
 
 
+def test_long_reference_1mb(oracle):
+    """BASELINE config 4 shape (1 Mb reference, k=9): the oracle needs a 1 GB matrix per read and strand, so three
+    reads; the GPU uses a larger checkpoint interval only if the budget says so (here it does not)."""
+    ref, flag, q, q_off, meta = synth.workload("r10_dna_1mb_q250", n_reads=3, seed=2)
+    with S.Aligner(ref, flag) as al:
+        got = al.align_db(q, q_off)
+        al.set_option("ckpt_budget_bytes", 1 << 20)   # force a large interval (few checkpoints)
+        got2 = al.align_db(q, q_off)
+        p2 = al.profile()
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=3)
+    assert_rows_equal(got, want)
+    assert_rows_equal(got2, want)
+    assert p2["ckpt_interval"] > 1024
+
+
+def test_many_batches_reuse_context(oracle):
+    """Buffers only grow; alternating big/small/empty batches through one context must not leak state."""
+    ref, flag, q, q_off, meta = synth.workload("sequin_r9_rna_q250", n_reads=40, seed=9)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=8)
+    with S.Aligner(ref, flag) as al:
+        for lo, hi in ((0, 40), (3, 4), (10, 10), (0, 17), (39, 40), (5, 33)):
+            got = al.align_db(q[q_off[lo]:q_off[hi]], q_off[lo:hi + 1] - q_off[lo])
+            assert got.tobytes() == want[lo:hi].tobytes()
+
+
 def test_align_events_entry(oracle):
     """align_db-shaped entry: AoS event tables + qstart/qend, as db_t holds them."""
     from sigfish_amd.api import EVENT_DTYPE
