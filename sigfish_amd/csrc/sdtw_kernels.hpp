@@ -147,15 +147,6 @@ struct Vec {
     typedef T type __attribute__((ext_vector_type(R)));
 };
 
-// The same pick as a select chain, for the handful of steps outside the steady-state loop.
-template <int R, typename T>
-__device__ __forceinline__ T pick_chain(const T (&a)[R], int idx) {
-    T out = a[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) out = (idx == r) ? a[r] : out;
-    return out;
-}
-
 // Running top-2 of the reference's candidate list for one read (kept in the registers of the lane that owns
 // the last query row).  Insertion rule of update_aln (src/sigfish.c:577-583): a candidate goes in front of
 // everything that is not strictly better, so on equal scores the LATER candidate ranks higher.
