@@ -76,7 +76,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SFA_DIST_FORCE") == "1"  # rehearse the RCCL path with one rank
+    if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- reference event model: built on rank 0, broadcast over RCCL/xGMI, resident in every rank's HBM ----
@@ -112,31 +113,30 @@ def main():
             fill_ms.append(p["fill_ms"])
             trace_ms.append(p["trace_ms"])
             launches += p["fill_launches"]
-        if world > 1:  # final gather of the result rows (24 B/read) to rank 0, in read order
+        if world > 1 or force_dist:  # final gather of the result rows (24 B/read) to rank 0, in read order
             D.gather_rows(d_out, counts)
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank != 0:
         al.close()
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     total_reads = n * world * args.steps
@@ -215,7 +215,7 @@ def main():
         out["speedup_vs_cpu_baseline"] = round(value / (sample / dt), 1)
     al.close()
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

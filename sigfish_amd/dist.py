@@ -6,11 +6,16 @@ The alignment stage shards embarrassingly over reads, so the data path has NO co
   * per batch: a gather of the fixed-size result rows (24 B/read) to rank 0, which writes PAF in read order.
 The same code runs over gloo on CPU tensors (tests) and over RCCL on GPU tensors (bench.py, N > 1).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import api
+
+# SFA_DIST_FORCE=1 runs the collectives even with a single rank (rehearsal of the RCCL path on a one-GPU box)
+_FORCE = os.environ.get("SFA_DIST_FORCE") == "1"
 
 
 def shard_range(n, rank, world):
@@ -24,7 +29,7 @@ def _dev(device):
 
 def broadcast_ref(ref, flag, device=None, src=0):
     """Rank `src` passes its RefModel (others pass None); every rank returns (RefModel, flag)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return ref, flag
     dev = _dev(device)
     rank = dist.get_rank()
@@ -44,7 +49,7 @@ def broadcast_ref(ref, flag, device=None, src=0):
     dist.broadcast(meta, src)
     dist.broadcast(levels, src)
     dist.broadcast_object_list(names, src)
-    if rank == src:
+    if rank == src and not _FORCE:
         return ref, flag
     m = meta.cpu().numpy()
     lens, offs, seql = m[:num_ref], m[num_ref:2 * num_ref], m[2 * num_ref:]
@@ -58,7 +63,7 @@ def broadcast_ref(ref, flag, device=None, src=0):
 def gather_rows(rows, counts, device=None, dst=0):
     """rows: this rank's result rows as a uint8 tensor [n_local*24] (GPU or CPU).  counts: reads per rank.
     Returns on `dst` a structured array with all rows in rank (= read) order, None elsewhere."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return np.frombuffer(rows.cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE)
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = rows.device
