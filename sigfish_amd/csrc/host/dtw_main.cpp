@@ -9,6 +9,7 @@
 #include <sys/time.h>
 
 #include <atomic>
+#include <future>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -238,17 +239,84 @@ int dtw_main(int argc, char **argv) {
         fprintf(stdout, "@PG\tID:sigfish\tPN:sigfish\tVN:0.2.0\n");
     }
 
-    // ---- batch loop, src/dtw_main.c:299-326 ----
+    // ---- batch loop, src/dtw_main.c:299-326, as a two-slot pipeline: while the GPU stage and the output of batch i
+    // run on a helper thread, the main thread loads and pre-processes batch i+1.  Batches are aligned and printed
+    // strictly in order, so the output is the same as the serial loop's. ----
     double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
     int64_t total = 0, prefix_fail = 0, ignored = 0, too_short = 0, sum_bytes = 0;
-    std::vector<Read> batch(o.batch_size);
-    std::vector<const sfa_event_t *> evp(o.batch_size);
-    std::vector<int64_t> nev(o.batch_size), qs(o.batch_size), qe(o.batch_size);
-    std::vector<sfa_result_t> rows(o.batch_size);
-    std::string line(4096, '\0');
+    struct Slot {
+        std::vector<Read> reads;
+        std::vector<const sfa_event_t *> evp;
+        std::vector<int64_t> nev, qs, qe;
+        std::vector<sfa_result_t> rows;
+        int32_t n = 0;
+        int64_t bytes = 0;
+    };
+    Slot slots[2];
+    for (Slot &sl : slots) {
+        sl.reads.resize(o.batch_size);
+        sl.evp.resize(o.batch_size);
+        sl.nev.resize(o.batch_size);
+        sl.qs.resize(o.batch_size);
+        sl.qe.resize(o.batch_size);
+        sl.rows.resize(o.batch_size);
+    }
+    auto align_and_output = [&](Slot &sl) {
+        const int32_t n = sl.n;
+        std::vector<Read> &batch = sl.reads;
+        std::vector<sfa_result_t> &rows = sl.rows;
+        double a = realtime();
+        if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK)
+            die(std::string("alignment failed: ") + sfa_last_error());
+        t_dtw += realtime() - a;
+        if (o.verbosity >= 4)
+            fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) processed\n", realtime() - t0, cputime() / (realtime() - t0), n, sl.bytes / 1e6);
+        a = realtime();
+        if (o.flag & F_SAM) {
+            // the warp path of every winner is rebuilt on the host from its band (sam.hpp), one read per task
+            std::vector<std::string> sam(n);
+            parallel_for(n, o.threads, [&](int64_t i) {
+                const Read &r = batch[i];
+                const sfa_result_t &row = rows[i];
+                if (!r.keep || !row.valid || row.rid < 0) return;
+                const float *y = row.strand == '+' ? fwd[row.rid].data() : rev[row.rid].data();
+                std::string buf(1 << 16, '\0');
+                int len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
+                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
+                if (len == SFA_ERANGE) {  // very long ss strings (full-reference alignments)
+                    buf.assign(1 << 22, '\0');
+                    len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
+                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
+                }
+                if (len > 0) sam[i].assign(buf.data(), len);
+            });
+            for (int32_t i = 0; i < n; ++i) fwrite(sam[i].data(), 1, sam[i].size(), stdout);
+        } else {
+            std::string line(4096, '\0');
+            for (int32_t i = 0; i < n; ++i) {  // output_db + aln_to_str, src/sigfish.c:796-826,1051-1086
+                const Read &r = batch[i];
+                if (!r.keep || !rows[i].valid || rows[i].rid < 0) continue;
+                const sfa_event_t &e0 = r.ev[r.qstart], &e1 = r.ev[r.qend - 1];
+                const uint64_t start_raw = e0.start;
+                const uint64_t end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
+                const int len = sfa_paf_row(&line[0], line.size(), &rows[i], r.rec.read_id.c_str(), contigs[rows[i].rid].name.c_str(),
+                                            start_raw, end_raw, static_cast<uint64_t>((r.qend - 1) - r.qstart), r.rec.raw.size(),
+                                            static_cast<uint64_t>(seq_len[rows[i].rid]));
+                if (len < 0) die("PAF line too long");
+                fwrite(line.data(), 1, len, stdout);
+            }
+        }
+        fflush(stdout);
+        t_out += realtime() - a;
+    };
+
+    std::future<void> pending;
+    int cur = 0;
     int32_t counter = 0;
     bool more = true;
     while (more) {
+        Slot &sl = slots[cur];
+        std::vector<Read> &batch = sl.reads;
         double a = realtime();
         int32_t n = 0;
         int64_t bytes = 0;
@@ -262,6 +330,8 @@ int dtw_main(int argc, char **argv) {
             bytes += static_cast<int64_t>(batch[n].mem.size());
             ++n;
         }
+        sl.n = n;
+        sl.bytes = bytes;
         t_load += realtime() - a;
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
@@ -290,67 +360,30 @@ int dtw_main(int argc, char **argv) {
         if (bad) die("error parsing a BLOW5 record");
         for (int32_t i = 0; i < n; ++i) {
             const Read &r = batch[i];
-            evp[i] = r.keep ? r.ev.data() : nullptr;
-            nev[i] = r.keep ? static_cast<int64_t>(r.ev.size()) : 0;
-            qs[i] = r.qstart;
-            qe[i] = r.qend;
+            sl.evp[i] = r.keep ? r.ev.data() : nullptr;
+            sl.nev[i] = r.keep ? static_cast<int64_t>(r.ev.size()) : 0;
+            sl.qs[i] = r.qstart;
+            sl.qe[i] = r.qend;
             prefix_fail += (r.status & 4) != 0;
             ignored += (r.status & 2) != 0;
             too_short += (r.status & 1) != 0;
         }
         t_proc += realtime() - a;
-        a = realtime();
-        if (n > 0 && sfa_align_events(ctx, evp.data(), nev.data(), qs.data(), qe.data(), n, rows.data()) != SFA_OK)
-            die(std::string("alignment failed: ") + sfa_last_error());
-        t_dtw += realtime() - a;
-        if (o.verbosity >= 4)
-            fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) processed\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
-        a = realtime();
-        if (o.flag & F_SAM) {
-            // the warp path of every winner is rebuilt on the host from its band (sam.hpp), one read per task
-            std::vector<std::string> sam(n);
-            parallel_for(n, o.threads, [&](int64_t i) {
-                const Read &r = batch[i];
-                const sfa_result_t &row = rows[i];
-                if (!r.keep || !row.valid || row.rid < 0) return;
-                const float *y = row.strand == '+' ? fwd[row.rid].data() : rev[row.rid].data();
-                std::string buf(1 << 16, '\0');
-                int len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
-                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
-                if (len == SFA_ERANGE) {  // very long ss strings (full-reference alignments)
-                    buf.assign(1 << 22, '\0');
-                    len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
-                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
-                }
-                if (len > 0) sam[i].assign(buf.data(), len);
-            });
-            for (int32_t i = 0; i < n; ++i) fwrite(sam[i].data(), 1, sam[i].size(), stdout);
-        } else
-        for (int32_t i = 0; i < n; ++i) {  // output_db + aln_to_str, src/sigfish.c:796-826,1051-1086
-            const Read &r = batch[i];
-            if (!r.keep || !rows[i].valid || rows[i].rid < 0) continue;
-            const sfa_event_t &e0 = r.ev[r.qstart], &e1 = r.ev[r.qend - 1];
-            const uint64_t start_raw = e0.start;
-            const uint64_t end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
-            const int len = sfa_paf_row(&line[0], line.size(), &rows[i], r.rec.read_id.c_str(), contigs[rows[i].rid].name.c_str(), start_raw,
-                                        end_raw, static_cast<uint64_t>((r.qend - 1) - r.qstart), r.rec.raw.size(),
-                                        static_cast<uint64_t>(seq_len[rows[i].rid]));
-            if (len < 0) die("PAF line too long");
-            fwrite(line.data(), 1, len, stdout);
-        }
-        fflush(stdout);
-        t_out += realtime() - a;
+        if (pending.valid()) pending.get();  // batch i-1 is out before batch i enters the GPU stage
+        pending = std::async(std::launch::async, [&align_and_output, &slots, cur] { align_and_output(slots[cur]); });
+        cur ^= 1;
         total += n;
         sum_bytes += bytes;
         if (o.debug_break == counter) break;
         ++counter;
     }
+    if (pending.valid()) pending.get();
     sfa_destroy(ctx);
     if (o.verbosity >= 3) {
         fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld\n", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);
         fprintf(stderr, "[dtw_main] total bytes: %.1f M\n[dtw_main] Data loading time: %.3f sec\n", sum_bytes / 1e6, t_load);
-        fprintf(stderr, "[dtw_main] Data processing time: %.3f sec\n[dtw_main]     - Parse+Events+Normalise time: %.3f sec\n[dtw_main]     - DTW time: %.3f sec\n",
-                t_proc + t_dtw, t_proc, t_dtw);
+        fprintf(stderr, "[dtw_main] Data processing time: %.3f sec (host stages) + %.3f sec (DTW stage, overlapped with the next batch)\n",
+                t_proc, t_dtw);
         fprintf(stderr, "[dtw_main] Data output time: %.3f sec\n", t_out);
     }
     return 0;
