@@ -165,6 +165,26 @@ int sfa_paf_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_i
                 uint64_t start_raw_idx, uint64_t end_raw_idx, uint64_t query_size, uint64_t len_raw_signal,
                 uint64_t rlength);
 
+/* ---- raw signal in, result rows out: the pre-DP stages on the GPU as well --------------------------------- */
+
+/* What the output writer needs besides the result row (aln_to_str, src/sigfish.c:796-826). */
+typedef struct {
+    int64_t n_events;       /* events detected in the read (0: read dropped) */
+    int64_t qstart, qend;   /* query window in events (src/sigfish.c:479-480) */
+    uint64_t start_raw_idx; /* event[qstart].start */
+    uint64_t end_raw_idx;   /* event[qend-1].start + length */
+    int32_t status;         /* bit 0: too short (kept), bit 1: ignored (dropped) */
+    int32_t pad;
+} sfa_query_info_t;
+
+/* process_db() for a whole batch on the device (src/sigfish.c:1018-1047 minus parsing): raw ADC samples -> pA ->
+ * event detection -> query window -> z-normalisation -> alignment.  raw: concatenated int16 samples, raw_off[n+1];
+ * scaling[3*i..]: digitisation, offset, range of read i (slow5 record fields).  prefix_size must be >= 0 (the RNA
+ * "-p -1" adaptor/poly-A detection stays on the host path: sfa_detect_events + sfa_select_query).
+ * rows[n] and info[n] are written in input order.  Blocking. */
+int sfa_align_raw(sfa_ctx_t *ctx, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n_reads,
+                  int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info);
+
 /* ---- host pre-DP stages and readers (no GPU needed) ----------------------------- */
 
 /* event_single (src/sigfish.c:330-378): raw ADC samples -> pA -> events (getevents, src/events.c:557-577).

@@ -34,12 +34,17 @@ class SfaPlanInfo(C.Structure):
                 ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64)]
 
 
+class SfaQueryInfo(C.Structure):
+    _fields_ = [("n_events", C.c_int64), ("qstart", C.c_int64), ("qend", C.c_int64), ("start_raw_idx", C.c_uint64),
+                ("end_raw_idx", C.c_uint64), ("status", C.c_int32), ("pad", C.c_int32)]
+
+
 class SfaEvent(C.Structure):
     _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float)]
 
 
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_sync",
+SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close"]
@@ -61,6 +66,7 @@ def load():
     L.sfa_align_batch.argtypes = [vp, f32p, i64p, C.c_int32, vp]
     L.sfa_align_batch_device.argtypes = [vp, vp, i64p, C.c_int32, vp, C.c_int]
     L.sfa_align_events.argtypes = [vp, C.POINTER(C.POINTER(SfaEvent)), i64p, i64p, i64p, C.c_int32, vp]
+    L.sfa_align_raw.argtypes = [vp, C.POINTER(C.c_int16), i64p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, vp, vp]
     L.sfa_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.sfa_plan_batch.argtypes = [i64p, C.c_int32, i32p, C.c_int32, C.c_int64, C.c_int64, i32p, C.POINTER(SfaPlanInfo)]
     L.sfa_sync.argtypes = [vp]

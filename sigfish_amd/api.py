@@ -19,6 +19,11 @@ RESULT_DTYPE = np.dtype([("rid", "<i4"), ("pos_st", "<i4"), ("pos_end", "<i4"), 
 assert RESULT_DTYPE.itemsize == C.sizeof(_lib.SfaResult)
 
 
+QUERY_INFO_DTYPE = np.dtype([("n_events", "<i8"), ("qstart", "<i8"), ("qend", "<i8"), ("start_raw_idx", "<u8"),
+                             ("end_raw_idx", "<u8"), ("status", "<i4"), ("pad", "<i4")])
+assert QUERY_INFO_DTYPE.itemsize == C.sizeof(_lib.SfaQueryInfo)
+
+
 class SfaError(RuntimeError):
     pass
 
@@ -190,6 +195,22 @@ class Aligner:
 
     def set_option(self, key, value):
         _check(self._L.sfa_set_option(self._h, key.encode(), int(value)), f"sfa_set_option({key})")
+
+    def align_raw(self, raw, raw_off, scaling, prefix_size=50, query_size=250):
+        """process_db on the device: raw int16 samples (concatenated) -> (rows, info).  scaling: float64 [n,3] =
+        digitisation, offset, range per read."""
+        raw = np.ascontiguousarray(raw, np.int16)
+        ro = np.ascontiguousarray(raw_off, np.int64)
+        sc = np.ascontiguousarray(scaling, np.float64).reshape(-1)
+        n = len(ro) - 1
+        rows = np.zeros(n, RESULT_DTYPE)
+        info = np.zeros(n, QUERY_INFO_DTYPE)
+        if raw.size == 0:
+            raw = np.zeros(1, np.int16)
+        _check(self._L.sfa_align_raw(self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), ro.ctypes.data_as(_lib.i64p),
+                                     sc.ctypes.data_as(C.POINTER(C.c_double)), n, prefix_size, query_size,
+                                     rows.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p)), "sfa_align_raw")
+        return rows, info
 
     def sync(self):
         _check(self._L.sfa_sync(self._h), "sfa_sync")

@@ -37,6 +37,7 @@ struct Opt {
     int32_t debug_break = -1;
     int verbosity = 4;
     int device = 0;
+    bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
     const char *model_file = nullptr;
     const char *pore = nullptr;
     int pore_flag = 0;  // 0 r9, 1 r10, 2 rna004
@@ -78,7 +79,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT               GPU to use [0]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT               GPU to use [0]\n   --host-events              detect events on host threads instead of the GPU\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -134,7 +135,7 @@ int dtw_main(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -167,6 +168,7 @@ int dtw_main(int argc, char **argv) {
                 if (!strcmp(optarg, "rna004")) { o.flag |= F_RNA | F_R10; o.pore_flag = 2; }
                 break;
             case 11: o.device = atoi(optarg); break;
+            case 14: o.host_events = true; break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }
     }
@@ -249,9 +251,16 @@ int dtw_main(int argc, char **argv) {
         std::vector<const sfa_event_t *> evp;
         std::vector<int64_t> nev, qs, qe;
         std::vector<sfa_result_t> rows;
+        // device-side event detection: concatenated raw samples + scaling instead of event tables
+        std::vector<int16_t> raw;
+        std::vector<int64_t> raw_off;
+        std::vector<double> scaling;
+        std::vector<sfa_query_info_t> info;
         int32_t n = 0;
         int64_t bytes = 0;
     };
+    // events on the GPU unless SAM (needs the event tables on the host) or the RNA auto prefix (adaptor/poly-A on host)
+    const bool gpu_events = !o.host_events && !(o.flag & F_SAM) && o.prefix >= 0;
     Slot slots[2];
     for (Slot &sl : slots) {
         sl.reads.resize(o.batch_size);
@@ -266,9 +275,20 @@ int dtw_main(int argc, char **argv) {
         std::vector<Read> &batch = sl.reads;
         std::vector<sfa_result_t> &rows = sl.rows;
         double a = realtime();
-        if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK)
+        if (gpu_events) {
+            sl.info.resize(n);
+            if (n > 0 && sfa_align_raw(ctx, sl.raw.data(), sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
+                                       sl.info.data()) != SFA_OK)
+                die(std::string("alignment failed: ") + sfa_last_error());
+        } else if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK) {
             die(std::string("alignment failed: ") + sfa_last_error());
+        }
         t_dtw += realtime() - a;
+        if (gpu_events)
+            for (int32_t i = 0; i < n; ++i) {
+                ignored += (sl.info[i].status & 2) != 0;
+                too_short += (sl.info[i].status & 1) != 0;
+            }
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) processed\n", realtime() - t0, cputime() / (realtime() - t0), n, sl.bytes / 1e6);
         a = realtime();
@@ -295,13 +315,21 @@ int dtw_main(int argc, char **argv) {
             std::string line(4096, '\0');
             for (int32_t i = 0; i < n; ++i) {  // output_db + aln_to_str, src/sigfish.c:796-826,1051-1086
                 const Read &r = batch[i];
-                if (!r.keep || !rows[i].valid || rows[i].rid < 0) continue;
-                const sfa_event_t &e0 = r.ev[r.qstart], &e1 = r.ev[r.qend - 1];
-                const uint64_t start_raw = e0.start;
-                const uint64_t end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
+                if (!rows[i].valid || rows[i].rid < 0) continue;
+                uint64_t start_raw, end_raw, qsize;
+                if (gpu_events) {
+                    start_raw = sl.info[i].start_raw_idx;
+                    end_raw = sl.info[i].end_raw_idx;
+                    qsize = static_cast<uint64_t>((sl.info[i].qend - 1) - sl.info[i].qstart);
+                } else {
+                    if (!r.keep) continue;
+                    const sfa_event_t &e0 = r.ev[r.qstart], &e1 = r.ev[r.qend - 1];
+                    start_raw = e0.start;
+                    end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
+                    qsize = static_cast<uint64_t>((r.qend - 1) - r.qstart);
+                }
                 const int len = sfa_paf_row(&line[0], line.size(), &rows[i], r.rec.read_id.c_str(), contigs[rows[i].rid].name.c_str(),
-                                            start_raw, end_raw, static_cast<uint64_t>((r.qend - 1) - r.qstart), r.rec.raw.size(),
-                                            static_cast<uint64_t>(seq_len[rows[i].rid]));
+                                            start_raw, end_raw, qsize, r.rec.raw.size(), static_cast<uint64_t>(seq_len[rows[i].rid]));
                 if (len < 0) die("PAF line too long");
                 fwrite(line.data(), 1, len, stdout);
             }
@@ -348,7 +376,7 @@ int dtw_main(int argc, char **argv) {
             r.ev.clear();
             r.status = 0;
             const int64_t ns = static_cast<int64_t>(r.rec.raw.size());
-            if (ns > 0) {  // event_single + normalise_single
+            if (ns > 0 && !gpu_events) {  // event_single + normalise_single
                 std::vector<float> pa(ns);
                 sfa::raw_to_picoamps(r.rec.raw.data(), ns, r.rec.digitisation, r.rec.offset, r.rec.range, pa.data());
                 r.ev = sfa::detect_events(pa.data(), ns, rna);
@@ -358,7 +386,22 @@ int dtw_main(int argc, char **argv) {
             }
         });
         if (bad) die("error parsing a BLOW5 record");
-        for (int32_t i = 0; i < n; ++i) {
+        if (gpu_events) {  // pack the samples of the batch for one upload
+            sl.raw_off.resize(n + 1);
+            sl.scaling.resize(3 * static_cast<size_t>(n));
+            sl.raw_off[0] = 0;
+            for (int32_t i = 0; i < n; ++i) {
+                sl.raw_off[i + 1] = sl.raw_off[i] + static_cast<int64_t>(batch[i].rec.raw.size());
+                sl.scaling[3 * i] = batch[i].rec.digitisation;
+                sl.scaling[3 * i + 1] = batch[i].rec.offset;
+                sl.scaling[3 * i + 2] = batch[i].rec.range;
+            }
+            sl.raw.resize(static_cast<size_t>(sl.raw_off[n]) + 1);
+            parallel_for(n, o.threads, [&](int64_t i) {
+                memcpy(sl.raw.data() + sl.raw_off[i], batch[i].rec.raw.data(), sizeof(int16_t) * batch[i].rec.raw.size());
+            });
+        }
+        for (int32_t i = 0; i < n && !gpu_events; ++i) {
             const Read &r = batch[i];
             sl.evp[i] = r.keep ? r.ev.data() : nullptr;
             sl.nev[i] = r.keep ? static_cast<int64_t>(r.ev.size()) : 0;

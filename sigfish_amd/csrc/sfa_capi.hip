@@ -19,6 +19,7 @@
 
 #include "../../include/sigfish_amd.h"
 #include "sdtw_kernels.hpp"
+#include "events_kernels.hpp"
 #include "sfa_plan.hpp"
 
 namespace {
@@ -123,6 +124,10 @@ struct sfa_ctx {
     // per-batch scratch
     DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_wscore, d_tst, d_ck, d_out;
     PinBuf h_stage, h_out;
+
+    // raw-signal path (sfa_align_raw)
+    DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
+        e_qoff, e_b0, e_b1, e_b2;
 
     sfa_profile_t prof{};
     bool prof_pending = false;
@@ -422,7 +427,9 @@ void sfa_destroy(sfa_ctx_t *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_ref, &c->d_job_off, &c->d_job_len, &c->d_job_contig, &c->d_job_strand, &c->d_ref_len, &c->d_ref_off,
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
-                      &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out})
+                      &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
+                      &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2})
         b->release();
     c->h_stage.release();
     c->h_out.release();
@@ -512,6 +519,150 @@ int sfa_align_events(sfa_ctx_t *c, const sfa_event_t *const *events, const int64
         for (int64_t j = 0; j < l; ++j) q[q_off[i] + j] = events[i][qstart[i] + j].mean;
     }
     return sfa_align_batch(c, q.data(), q_off.data(), n, out);
+}
+
+int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n, int32_t prefix_size,
+                  int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info) {
+    if (!c || n < 0 || (n > 0 && (!raw || !raw_off || !scaling || !rows || !info))) return fail(SFA_EINVAL, "sfa_align_raw: bad argument");
+    if (prefix_size < 0) return fail(SFA_EINVAL, "sfa_align_raw: automatic query start (-p -1) needs the host stages");
+    if (query_size <= 0) return fail(SFA_EINVAL, "sfa_align_raw: query_size must be positive");
+    if (n == 0) return SFA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t total = raw_off[n] - raw_off[0];
+    if (total < 0 || raw_off[0] != 0) return fail(SFA_EINVAL, "sfa_align_raw: raw_off must start at 0 and be monotone");
+    const bool rna = (c->flag & SFA_RNA) != 0;
+    hipStream_t st = c->stream;
+    // event capacity per read: every sample can close at most one event per detector, each detector at most every
+    // second sample -> n samples bound the count
+    std::vector<int64_t> ev_off(n + 1);
+    std::vector<float> scale(2 * static_cast<size_t>(n));
+    ev_off[0] = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t len = raw_off[i + 1] - raw_off[i];
+        if (len < 0) return fail(SFA_EINVAL, "sfa_align_raw: raw_off not monotone at read %d", i);
+        ev_off[i + 1] = ev_off[i] + len + 2;
+        const float range = static_cast<float>(scaling[3 * i + 2]), dig = static_cast<float>(scaling[3 * i]);
+        scale[2 * i] = static_cast<float>(scaling[3 * i + 1]);
+        scale[2 * i + 1] = range / dig;  // event_single(), src/sigfish.c:343
+    }
+    const int64_t ev_total = ev_off[n];
+    int rc;
+    if ((rc = c->e_raw.reserve(2 * (size_t)std::max<int64_t>(total, 1))) || (rc = c->e_rawoff.reserve(8 * (size_t)(n + 1))) ||
+        (rc = c->e_scale.reserve(8 * (size_t)n)) || (rc = c->e_sum.reserve(8 * (size_t)(total + n))) ||
+        (rc = c->e_sumsq.reserve(8 * (size_t)(total + n))) || (rc = c->e_t1.reserve(4 * (size_t)std::max<int64_t>(total, 1))) ||
+        (rc = c->e_t2.reserve(4 * (size_t)std::max<int64_t>(total, 1))) || (rc = c->e_evoff.reserve(8 * (size_t)(n + 1))) ||
+        (rc = c->e_evstart.reserve(4 * (size_t)ev_total)) || (rc = c->e_evlen.reserve(4 * (size_t)ev_total)) ||
+        (rc = c->e_evmean.reserve(4 * (size_t)ev_total)) || (rc = c->e_evstdv.reserve(4 * (size_t)ev_total)) ||
+        (rc = c->e_nev.reserve(4 * (size_t)n)) || (rc = c->e_qstart.reserve(8 * (size_t)n)) || (rc = c->e_qoff.reserve(8 * (size_t)(n + 1))) ||
+        (rc = c->e_b0.reserve(4 * (size_t)n)) || (rc = c->e_b1.reserve(4 * (size_t)n)) || (rc = c->e_b2.reserve(4 * (size_t)n)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c->e_raw.p, raw, 2 * (size_t)total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->e_scale.p, scale.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->e_evoff.p, ev_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+
+    sfa::EvArgs ea{};
+    ea.raw = c->e_raw.as<int16_t>();
+    ea.raw_off = c->e_rawoff.as<int64_t>();
+    ea.scale = c->e_scale.as<float>();
+    ea.sum = c->e_sum.as<double>();
+    ea.sumsq = c->e_sumsq.as<double>();
+    ea.t1 = c->e_t1.as<float>();
+    ea.t2 = c->e_t2.as<float>();
+    ea.ev_off = c->e_evoff.as<int64_t>();
+    ea.ev_start = c->e_evstart.as<int32_t>();
+    ea.ev_length = c->e_evlen.as<float>();
+    ea.ev_mean = c->e_evmean.as<float>();
+    ea.ev_stdv = c->e_evstdv.as<float>();
+    ea.n_events = c->e_nev.as<int32_t>();
+    ea.n_reads = n;
+    // detector parameters, src/events.c:47-58
+    ea.w1 = rna ? 7 : 3;
+    ea.w2 = rna ? 14 : 6;
+    ea.thr1 = rna ? 2.5f : 1.4f;
+    ea.thr2 = 9.0f;
+    ea.peak_height = rna ? 1.0f : 0.2f;
+    const dim3 lane_grid((n + 63) / 64), lane_block(64);
+    hipLaunchKernelGGL(sfa::ev_prefix_kernel, lane_grid, lane_block, 0, st, ea);
+    hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, st, ea);
+    hipLaunchKernelGGL(sfa::ev_peaks_kernel, lane_grid, lane_block, 0, st, ea);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> nev(n);
+    HIP_TRY(hipMemcpyAsync(nev.data(), c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // query windows on the host (normalise_single, src/sigfish.c:433-480); the arithmetic part runs on the device
+    std::vector<int64_t> qstart(n), q_off(n + 1);
+    q_off[0] = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t ne = nev[i];
+        int64_t s0 = 0, e0 = 0;
+        int status = 0;
+        bool keep = ne > 0 && (raw_off[i + 1] - raw_off[i]) > 0;
+        if (keep) {
+            if (!(c->flag & SFA_END)) {
+                s0 = prefix_size;
+                e0 = s0 + query_size;
+                if (s0 + 25 > ne) {
+                    s0 = e0 = 0;
+                    keep = false;
+                    status |= 2;
+                } else if (e0 > ne) {
+                    e0 = ne;
+                    status |= 1;
+                }
+            } else {
+                s0 = ne - prefix_size - query_size;
+                e0 = ne - prefix_size;
+                if (s0 < 0) {
+                    s0 = 0;
+                    status |= 1;
+                }
+                if (e0 < 0) {
+                    e0 = 0;
+                    keep = false;
+                    status |= 2;
+                }
+            }
+        }
+        if (!keep) s0 = e0 = 0;
+        qstart[i] = s0;
+        q_off[i + 1] = q_off[i] + (e0 - s0);
+        info[i].n_events = ne;
+        info[i].qstart = s0;
+        info[i].qend = e0;
+        info[i].status = status;
+        info[i].pad = 0;
+    }
+    const int64_t nq = q_off[n];
+    if ((rc = c->d_queries.reserve(4 * (size_t)std::max<int64_t>(nq, 1))) || (rc = c->d_out.reserve(sizeof(sfa_result_t) * (size_t)n)) ||
+        (rc = c->h_out.reserve(sizeof(sfa_result_t) * (size_t)n)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c->e_qstart.p, qstart.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->e_qoff.p, q_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    sfa::QueryArgs qa{c->e_evmean.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(), c->e_qoff.as<int64_t>(),
+                      c->d_queries.as<float>(), n};
+    hipLaunchKernelGGL(sfa::ev_query_kernel, lane_grid, lane_block, 0, st, qa);
+    sfa::BoundsArgs ba{c->e_evstart.as<int32_t>(), c->e_evlen.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(),
+                       c->e_qoff.as<int64_t>(), c->e_b0.as<int32_t>(), c->e_b1.as<int32_t>(), c->e_b2.as<float>(), n};
+    hipLaunchKernelGGL(sfa::ev_bounds_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ba);
+    HIP_TRY(hipGetLastError());
+    // the queries must be complete before align_device's uploads reuse the pinned staging area; same stream, in order
+    if ((rc = align_device(c, c->d_queries.as<float>(), q_off.data(), n, c->d_out.as<ResultRow>()))) return rc;
+    std::vector<int32_t> b0(n), b1(n);
+    std::vector<float> b2(n);
+    HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_out.p, sizeof(sfa_result_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b0.data(), c->e_b0.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b1.data(), c->e_b1.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b2.data(), c->e_b2.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(rows, c->h_out.p, sizeof(sfa_result_t) * (size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        info[i].start_raw_idx = static_cast<uint64_t>(b0[i]);
+        info[i].end_raw_idx = static_cast<uint64_t>(static_cast<float>(static_cast<uint64_t>(b1[i])) + b2[i]);  // u64 + float, as in C
+    }
+    return resolve_profile(c);
 }
 
 int sfa_sync(sfa_ctx_t *c) {

@@ -40,6 +40,17 @@ def test_cli_matches_reference_output(name, models):
     assert r.stdout.decode() == c["out_text"]
 
 
+@pytest.mark.parametrize("name", ["dna_default", "dna_from_end", "rna_default", "rna_full_ref_dtw_std"])
+def test_cli_host_events_path(name, models):
+    """--host-events forces event detection onto host threads; output must be identical to the default (GPU) path."""
+    c = load_case(name)
+    args = [str(a) for a in c["args"]]
+    cmd = [BIN, "dtw", "--kmer-model", models[c["k"]], "--verbose", "0", "--host-events", *args, c["fasta"], c["blow5"]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+
+
 def test_cli_small_batches_keep_order(models):
     """-K 2 forces several batches; output order and content must not change."""
     c = load_case("rna_default")
