@@ -1,0 +1,16 @@
+// sdtw_instances.hpp -- the DP kernels are instantiated in their own translation units (sdtw_inst_*.hip) so that
+// the build can compile them in parallel; everybody else only sees these declarations.
+#pragma once
+#include "sdtw_kernels.hpp"
+
+namespace sfa {
+#define SFA_FILL_DECL(MR, TR, SD) extern template __global__ void sdtw_fill_kernel<MR, TR, SD>(const DpArgs);
+#define SFA_TRACE_DECL(MR, SD) extern template __global__ void sdtw_trace_kernel<MR, SD>(const DpArgs, int32_t *);
+#define SFA_FOR_MAXR(X, ...) X(4, __VA_ARGS__) X(8, __VA_ARGS__) X(16, __VA_ARGS__) X(32, __VA_ARGS__)
+SFA_FOR_MAXR(SFA_FILL_DECL, false, false)
+SFA_FOR_MAXR(SFA_FILL_DECL, false, true)
+SFA_FOR_MAXR(SFA_FILL_DECL, true, false)
+SFA_FOR_MAXR(SFA_FILL_DECL, true, true)
+SFA_FOR_MAXR(SFA_TRACE_DECL, false)
+SFA_FOR_MAXR(SFA_TRACE_DECL, true)
+}  // namespace sfa

@@ -376,7 +376,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
 template <int R, bool TRACK, bool STD, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
                                                const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T) {
-    if constexpr (TRACK || STD) {
+    if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
         sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
     } else {
         if (rq == I) {
@@ -654,6 +654,7 @@ __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
     return static_cast<uint8_t>(q);
 }
 
+#ifdef SFA_DEFINE_FINALIZE_KERNEL  // a plain (non-template) kernel: defined in exactly one translation unit
 __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_reads) return;
@@ -726,5 +727,6 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     }
     a.out[i] = r;
 }
+#endif
 
 }  // namespace sfa

@@ -18,8 +18,10 @@
 #include <vector>
 
 #include "../../include/sigfish_amd.h"
+#define SFA_DEFINE_FINALIZE_KERNEL
 #include "sdtw_kernels.hpp"
 #include "events_kernels.hpp"
+#include "sdtw_instances.hpp"
 #include "sfa_plan.hpp"
 
 namespace {
