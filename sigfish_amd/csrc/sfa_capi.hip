@@ -511,8 +511,13 @@ int sfa_align_events(sfa_ctx_t *c, const sfa_event_t *const *events, const int64
     // gather db->et[i].event[qstart..qend).mean (AoS, stride 24 B) into the packed SoA the kernels read
     std::vector<int64_t> q_off(n + 1, 0);
     for (int32_t i = 0; i < n; ++i) {
-        int64_t l = (n_events[i] > 0 && events[i]) ? qend[i] - qstart[i] : 0;
-        if (l < 0) l = 0;
+        int64_t l = 0;
+        if (n_events[i] > 0 && events[i]) {
+            if (qstart[i] < 0 || qend[i] < qstart[i] || qend[i] > n_events[i])
+                return fail(SFA_EINVAL, "sfa_align_events: read %d has query window [%lld,%lld) outside its %lld events", i,
+                            (long long)qstart[i], (long long)qend[i], (long long)n_events[i]);
+            l = qend[i] - qstart[i];
+        }
         q_off[i + 1] = q_off[i] + l;
     }
     std::vector<float> q(std::max<int64_t>(q_off[n], 1));

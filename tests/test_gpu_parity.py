@@ -221,6 +221,17 @@ def test_full_size_properties():
     assert (a["score2"] >= a["score"]).all()
 
 
+def test_bad_query_window_is_rejected():
+    from sigfish_amd.api import EVENT_DTYPE
+    ref = _small_ref(np.random.default_rng(0), [50], False)
+    t = np.zeros(30, EVENT_DTYPE)
+    with S.Aligner(ref, 0) as al:
+        with pytest.raises(S.SfaError, match="outside"):
+            al.align_events([t], [10], [31])
+        with pytest.raises(S.SfaError, match="outside"):
+            al.align_events([t], [-1], [20])
+
+
 def test_no_device_fallback_is_loud():
     ref = _small_ref(np.random.default_rng(0), [50], False)
     with pytest.raises(S.SfaError):
