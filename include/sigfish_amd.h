@@ -185,6 +185,11 @@ typedef struct {
 int sfa_align_raw(sfa_ctx_t *ctx, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n_reads,
                   int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info);
 
+/* Page-locked host memory for the buffers handed to sfa_align_raw / sfa_align_batch (uploads from pageable memory
+ * run at a fraction of the PCIe rate).  Plain malloc-style pair; NULL on failure. */
+void *sfa_pinned_alloc(size_t bytes);
+void sfa_pinned_free(void *p);
+
 /* ---- host pre-DP stages and readers (no GPU needed) ----------------------------- */
 
 /* event_single (src/sigfish.c:330-378): raw ADC samples -> pA -> events (getevents, src/events.c:557-577).

@@ -44,7 +44,7 @@ class SfaEvent(C.Structure):
 
 
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_sync",
+SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close"]
@@ -67,6 +67,10 @@ def load():
     L.sfa_align_batch_device.argtypes = [vp, vp, i64p, C.c_int32, vp, C.c_int]
     L.sfa_align_events.argtypes = [vp, C.POINTER(C.POINTER(SfaEvent)), i64p, i64p, i64p, C.c_int32, vp]
     L.sfa_align_raw.argtypes = [vp, C.POINTER(C.c_int16), i64p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    L.sfa_pinned_alloc.argtypes = [C.c_size_t]
+    L.sfa_pinned_alloc.restype = vp
+    L.sfa_pinned_free.argtypes = [vp]
+    L.sfa_pinned_free.restype = None
     L.sfa_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.sfa_plan_batch.argtypes = [i64p, C.c_int32, i32p, C.c_int32, C.c_int64, C.c_int64, i32p, C.POINTER(SfaPlanInfo)]
     L.sfa_sync.argtypes = [vp]

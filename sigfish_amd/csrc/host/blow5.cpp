@@ -2,6 +2,8 @@
 // like a reference binary built without zstd=1).
 #include "blow5.hpp"
 
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <cstring>
@@ -69,6 +71,9 @@ bool decode_svb_zd(const uint8_t *p, size_t nbytes, std::vector<int16_t> *out) {
 }  // namespace
 
 void Blow5Reader::close() {
+    if (map_) munmap(const_cast<uint8_t *>(map_), map_size_);
+    map_ = nullptr;
+    map_size_ = map_pos_ = 0;
     if (fp_) fclose(fp_);
     fp_ = nullptr;
 }
@@ -124,7 +129,37 @@ bool Blow5Reader::open(const std::string &path) {
         }
         pos = eol + 1;
     }
+    // map the file for the zero-copy record iterator; plain fread keeps working if this fails (pipes, odd filesystems)
+    struct stat sb;
+    if (fstat(fileno(fp_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+        void *m = mmap(nullptr, static_cast<size_t>(sb.st_size), PROT_READ, MAP_PRIVATE, fileno(fp_), 0);
+        if (m != MAP_FAILED) {
+            map_ = static_cast<const uint8_t *>(m);
+            map_size_ = static_cast<size_t>(sb.st_size);
+            map_pos_ = 68 + static_cast<size_t>(hsize);
+            madvise(m, map_size_, MADV_SEQUENTIAL);
+        }
+    }
     return true;
+}
+
+int Blow5Reader::next_view(const uint8_t **mem, size_t *size) {
+    if (!map_) return -2;  // caller falls back to next_mem()
+    if (map_pos_ + sizeof kEof <= map_size_ && map_size_ - map_pos_ == sizeof kEof && memcmp(map_ + map_pos_, kEof, sizeof kEof) == 0) return 0;
+    if (map_pos_ + 8 > map_size_) {
+        err_ = "malformed BLOW5: missing end-of-file marker";
+        return -1;
+    }
+    uint64_t sz;
+    memcpy(&sz, map_ + map_pos_, 8);
+    if (sz > map_size_ - map_pos_ - 8) {
+        err_ = "malformed BLOW5: truncated record";
+        return -1;
+    }
+    *mem = map_ + map_pos_ + 8;
+    *size = static_cast<size_t>(sz);
+    map_pos_ += 8 + static_cast<size_t>(sz);
+    return 1;
 }
 
 int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
@@ -145,11 +180,15 @@ int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
 }
 
 bool Blow5Reader::parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::string *err) const {
-    rec->record_bytes = mem.size();
+    return parse(mem.data(), mem.size(), rec, err);
+}
+
+bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const {
+    rec->record_bytes = size;
     std::vector<uint8_t> inflated;
-    const uint8_t *p = mem.data(), *end = p + mem.size();
+    const uint8_t *p = mem, *end = p + size;
     if (record_press_ == 1) {
-        if (!inflate_all(mem.data(), mem.size(), &inflated)) {
+        if (!inflate_all(mem, size, &inflated)) {
             *err = "malformed BLOW5: record does not inflate";
             return false;
         }

@@ -38,6 +38,9 @@ class Blow5Reader {
     // slow5_get_next_mem in load_db, slow5_rec_depress_parse in parse_single, src/sigfish.c:289,322)
     int next_mem(std::vector<uint8_t> *mem);
     bool parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::string *err) const;
+    // zero-copy variant: the file is mapped, a record is a (pointer, size) view into the mapping (valid until close())
+    int next_view(const uint8_t **mem, size_t *size);
+    bool parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const;
     // first value (read group 0) of a header attribute, or nullptr (slow5_hdr_get(attr, 0, hdr))
     const char *attr(const std::string &key) const;
     uint32_t num_read_groups() const { return n_groups_; }
@@ -45,6 +48,8 @@ class Blow5Reader {
 
   private:
     FILE *fp_ = nullptr;
+    const uint8_t *map_ = nullptr;  // whole file, read-only mapping (nullptr: mmap unavailable, fall back to fread)
+    size_t map_size_ = 0, map_pos_ = 0;
     uint8_t record_press_ = 0, signal_press_ = 0;
     uint32_t n_groups_ = 1;
     std::map<std::string, std::string> attrs_;

@@ -92,7 +92,9 @@ void help(FILE *fp, const Opt &o) {
 }
 
 struct Read {
-    std::vector<uint8_t> mem;
+    std::vector<uint8_t> mem;          // record bytes when the file cannot be mapped
+    const uint8_t *view = nullptr;     // record bytes inside the mapped file otherwise
+    size_t view_size = 0;
     sfa::Blow5Record rec;
     std::vector<sfa_event_t> ev;
     int64_t qstart = 0, qend = 0;
@@ -252,7 +254,8 @@ int dtw_main(int argc, char **argv) {
         std::vector<int64_t> nev, qs, qe;
         std::vector<sfa_result_t> rows;
         // device-side event detection: concatenated raw samples + scaling instead of event tables
-        std::vector<int16_t> raw;
+        int16_t *raw = nullptr;  // page-locked (sfa_pinned_alloc), grown on demand
+        size_t raw_cap = 0;
         std::vector<int64_t> raw_off;
         std::vector<double> scaling;
         std::vector<sfa_query_info_t> info;
@@ -277,7 +280,7 @@ int dtw_main(int argc, char **argv) {
         double a = realtime();
         if (gpu_events) {
             sl.info.resize(n);
-            if (n > 0 && sfa_align_raw(ctx, sl.raw.data(), sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
+            if (n > 0 && sfa_align_raw(ctx, sl.raw, sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
                                        sl.info.data()) != SFA_OK)
                 die(std::string("alignment failed: ") + sfa_last_error());
         } else if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK) {
@@ -349,13 +352,18 @@ int dtw_main(int argc, char **argv) {
         int32_t n = 0;
         int64_t bytes = 0;
         while (n < o.batch_size && bytes < o.batch_bytes) {
-            const int rc = reader.next_mem(&batch[n].mem);
+            int rc = reader.next_view(&batch[n].view, &batch[n].view_size);
+            if (rc == -2) {  // not mappable: copy the record
+                batch[n].view = nullptr;
+                rc = reader.next_mem(&batch[n].mem);
+                batch[n].view_size = batch[n].mem.size();
+            }
             if (rc < 0) die(reader.error());
             if (rc == 0) {
                 more = false;
                 break;
             }
-            bytes += static_cast<int64_t>(batch[n].mem.size());
+            bytes += static_cast<int64_t>(batch[n].view_size);
             ++n;
         }
         sl.n = n;
@@ -368,7 +376,7 @@ int dtw_main(int argc, char **argv) {
         parallel_for(n, o.threads, [&](int64_t i) {
             Read &r = batch[i];
             std::string perr;
-            if (!reader.parse(r.mem, &r.rec, &perr)) {
+            if (!(r.view ? reader.parse(r.view, r.view_size, &r.rec, &perr) : reader.parse(r.mem, &r.rec, &perr))) {
                 bad = 1;
                 return;
             }
@@ -396,9 +404,15 @@ int dtw_main(int argc, char **argv) {
                 sl.scaling[3 * i + 1] = batch[i].rec.offset;
                 sl.scaling[3 * i + 2] = batch[i].rec.range;
             }
-            sl.raw.resize(static_cast<size_t>(sl.raw_off[n]) + 1);
+            const size_t need = static_cast<size_t>(sl.raw_off[n]) + 1;
+            if (need > sl.raw_cap) {
+                sfa_pinned_free(sl.raw);
+                sl.raw_cap = need + need / 4;
+                sl.raw = static_cast<int16_t *>(sfa_pinned_alloc(sl.raw_cap * sizeof(int16_t)));
+                if (!sl.raw) die(std::string("cannot allocate the sample staging buffer: ") + sfa_last_error());
+            }
             parallel_for(n, o.threads, [&](int64_t i) {
-                memcpy(sl.raw.data() + sl.raw_off[i], batch[i].rec.raw.data(), sizeof(int16_t) * batch[i].rec.raw.size());
+                memcpy(sl.raw + sl.raw_off[i], batch[i].rec.raw.data(), sizeof(int16_t) * batch[i].rec.raw.size());
             });
         }
         for (int32_t i = 0; i < n && !gpu_events; ++i) {
@@ -421,6 +435,7 @@ int dtw_main(int argc, char **argv) {
         ++counter;
     }
     if (pending.valid()) pending.get();
+    for (Slot &sl : slots) sfa_pinned_free(sl.raw);
     sfa_destroy(ctx);
     if (o.verbosity >= 3) {
         fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld\n", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);

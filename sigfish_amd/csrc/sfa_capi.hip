@@ -672,6 +672,19 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     return resolve_profile(c);
 }
 
+void *sfa_pinned_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(SFA_ENOMEM, "hipHostMalloc(%zu bytes) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void sfa_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int sfa_sync(sfa_ctx_t *c) {
     if (!c) return fail(SFA_EINVAL, "null context");
     HIP_TRY(hipSetDevice(c->device));
