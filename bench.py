@@ -15,8 +15,9 @@ The JSON line also carries
   roofline      HBM roofline of the dominant kernel (sdtw_fill_kernel): algorithmic bytes per launch / its mean
                 duration, measured with HIP events on the stream the kernel is launched on; plus the VALU view
                 (cells/s vs lanes*clock/ops_per_cell), which is the bound that actually bites.
-  cpu_baseline  the oracle (CPU restatement of the reference algorithm, pthread fan-out) timed on this box's host
-                cores on a bounded sample of the same workload; kind "port".
+  cpu_baseline  sigfish's own CPU alignment stage (the reference sources compiled into oracle/_ref; kind "reference")
+                timed on this box's host cores on a bounded sample of the same workload; falls back to our CPU
+                restatement (kind "port") when that build is absent.
 """
 import argparse
 import json
@@ -194,22 +195,30 @@ def main():
             al.align_db(q, q_off)
         out["pcie_inclusive_reads_per_s"] = round(n * args.steps / (time.perf_counter() - t1), 1)
 
-    # ---- CPU baseline: the oracle on a bounded sample of this rank's reads, all host cores -----------------
+    # ---- CPU baseline on a bounded sample of this rank's reads, all host cores of this box ---------------------
+    # kind "reference": the reference's OWN align_db (dtw_single over work_db), compiled from its sources into
+    # oracle/_ref (travels with the repo); kind "port": our CPU restatement, when that build is not there.
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # checker / baseline only
         cores = host_cores()
         oref = O.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
-        pilot = min(n, cores * 2)
-        t1 = time.perf_counter()
-        O.align_batch(q, q_off[:pilot + 1], oref, flag, threads=cores)
-        rate = pilot / (time.perf_counter() - t1)
-        sample = int(max(pilot, min(n, rate * args.cpu_seconds)))
-        t1 = time.perf_counter()
-        want = O.align_batch(q, q_off[:sample + 1], oref, flag, threads=cores)
-        dt = time.perf_counter() - t1
+        use_ref = os.path.exists(O.REF_BENCH)
+
+        def cpu_run(m):
+            if use_ref:
+                return O.reference_align_batch(q, q_off[:m + 1], oref, flag, threads=cores)
+            t1 = time.perf_counter()
+            rows = O.align_batch(q, q_off[:m + 1], oref, flag, threads=cores)
+            return rows, time.perf_counter() - t1
+
+        pilot = min(n, cores * 4)
+        _, pdt = cpu_run(pilot)
+        sample = int(max(pilot, min(n, pilot / pdt * args.cpu_seconds)))
+        want, dt = cpu_run(sample)
         got = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=S.RESULT_DTYPE)[:sample]
-        out["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "reads/s", "cores": cores, "kind": "port",
-                               "sample": f"first {sample} reads of the same batch, {dt:.1f} s wall, "
+        out["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "reads/s", "cores": cores,
+                               "kind": "reference" if use_ref else "port",
+                               "sample": f"first {sample} reads of the same batch, {dt:.1f} s wall in the alignment stage, "
                                          f"{int(lens[:sample].sum()) * cols / dt:.3e} cells/s",
                                "parity_on_sample": bool(got.tobytes() == want.tobytes())}
         out["speedup_vs_cpu_baseline"] = round(value / (sample / dt), 1)

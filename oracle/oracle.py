@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsigfish_ref.so")
 REF_DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+REF_BENCH = os.path.join(HERE, "_ref", "ref_bench")
 
 RNA, DTW, INV, REF, END = 0x001, 0x002, 0x004, 0x010, 0x020
 
@@ -324,3 +325,34 @@ def parse_dump(path):
                        score=np.float32(sc), score2=np.float32(sc2), strand=d, mapq=mq)
         reads.append(rec)
     return dict(flag=flag, rna=bool(rna), ref=ref, reads=reads)
+
+
+def reference_align_batch(events, q_off, ref, flag, threads=1, workdir="/tmp"):
+    """Run the COMPILED REFERENCE's align_db (dtw_single over work_db) through oracle/_ref/ref_bench.
+    Returns (rows, seconds) or None when the reference build is not available."""
+    if not os.path.exists(REF_BENCH):
+        return None
+    ev = _f32(events)
+    q_off = np.ascontiguousarray(q_off, np.int64)
+    n = len(q_off) - 1
+    fin = os.path.join(workdir, f"sfa_refbench_{os.getpid()}.in")
+    fout = fin[:-3] + ".out"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<4i", flag, ref.num_ref, n, threads))
+        for i in range(ref.num_ref):
+            f.write(struct.pack("<3i", int(ref.ref_lengths[i]), int(ref.seq_lengths[i]), int(ref.st_offset[i])))
+            f.write(_f32(ref.forward[i]).tobytes())
+            if ref.reverse is not None:
+                f.write(_f32(ref.reverse[i]).tobytes())
+        f.write(q_off.tobytes())
+        f.write(ev[:int(q_off[-1])].tobytes())
+    try:
+        subprocess.run([REF_BENCH, fin, fout], check=True, capture_output=True)
+        b = open(fout, "rb").read()
+    finally:
+        for p in (fin, fout):
+            if os.path.exists(p):
+                os.remove(p)
+    (secs,) = struct.unpack_from("<d", b, 0)
+    rows = np.frombuffer(b, RESULT_DTYPE, n, 8).copy()
+    return rows, secs

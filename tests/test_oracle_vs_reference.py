@@ -38,3 +38,17 @@ def test_driver_reproduces_golden(name, tmp_path):
            *[str(a) for a in c["args"]], c["fasta"], c["blow5"]]
     out = subprocess.run(cmd, check=True, capture_output=True).stdout.decode()
     assert out == c["out_text"]
+
+
+@pytest.mark.parametrize("wl,n", [("ncov_r9_dna_q250", 12), ("sequin_r9_rna_q250", 16), ("rna004_fullref_dtwstd_q250", 8)])
+def test_reference_align_db_on_synthetic_workloads(wl, n):
+    """The reference's own dtw_single/work_db (oracle/_ref/ref_bench) on the synthetic BASELINE workloads: the oracle
+    must produce the same rows -- this pins the checker used by the GPU tests on inputs the fixtures do not cover."""
+    from sigfish_amd import synth
+    ref, flag, q, q_off, meta = synth.workload(wl, n_reads=n, seed=21)
+    oref = O.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
+    got = O.reference_align_batch(q, q_off, oref, flag, threads=4)
+    assert got is not None
+    rows, secs = got
+    want = O.align_batch(q, q_off, oref, flag, threads=4)
+    assert rows.tobytes() == want.tobytes() and secs > 0
