@@ -42,7 +42,7 @@ enum {
     SFA_EKERNEL = -5  /* kernel launch or execution failed */
 };
 
-#define SFA_MAX_QUERY 512 /* longest query (events) a single read may have */
+#define SFA_MAX_QUERY 2048 /* longest query (events) a single read may have */
 
 /* Reference event model: the fields of refsynth_t (src/sigfish.h:90-99) the alignment stage reads. */
 typedef struct {
@@ -92,7 +92,8 @@ typedef struct {
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */
 typedef struct {
-    int32_t n_quads;          /* wavefronts' worth of reads: groups of <= 4 reads with the same query length */
+    int32_t n_quads;          /* wavefronts' worth of reads: groups of <= 4 reads with the same query length (<= 2 / 1
+                                 reads for queries longer than 512 / 1024 events) */
     int32_t n_chunks;
     int32_t n_classes;        /* rows-per-lane classes present */
     int32_t max_rows_per_lane;
@@ -100,6 +101,8 @@ typedef struct {
     int32_t trace_margin;
     int64_t ckpt_bytes;
     int64_t n_tasks;
+    int32_t max_lanes_per_read; /* 16, or 32 / 64 when queries longer than 512 / 1024 events are present */
+    int32_t reserved;
 } sfa_plan_info_t;
 
 /* Create a context on HIP device `device`, copy the reference event arrays into HBM.

@@ -46,6 +46,7 @@ CASES = [
     ("dna_q100", "nCoV-2019.reference.fasta", "sp1_dna.blow5", 6, ["-q", "100"]),
     ("dna_q300_p10", "nCoV-2019.reference.fasta", "sp1_dna.blow5", 6, ["-q", "300", "-p", "10"]),
     ("dna_sam", "nCoV-2019.reference.fasta", "sp1_dna.blow5", 6, ["--sam"]),
+    ("dna_q700", "nCoV-2019.reference.fasta", "sp1_dna.blow5", 6, ["-q", "700"]),
     ("rna_default", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna"]),
     ("rna_q500_pauto", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "500", "-p", "-1"]),
     ("rna_full_ref", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "--full-ref"]),
@@ -55,6 +56,8 @@ CASES = [
     ("rna_from_end", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "--from-end"]),
     ("rna_invert", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "--invert"]),
     ("rna_sam", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "--sam"]),
+    ("rna_q1000", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "1000", "--full-ref"]),
+    ("rna_q2000_sam", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "2000", "--full-ref", "--sam"]),
 ]
 
 

@@ -31,7 +31,8 @@ class SfaProfile(C.Structure):
 class SfaPlanInfo(C.Structure):
     _fields_ = [("n_quads", C.c_int32), ("n_chunks", C.c_int32), ("n_classes", C.c_int32),
                 ("max_rows_per_lane", C.c_int32), ("ckpt_interval", C.c_int32), ("trace_margin", C.c_int32),
-                ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64)]
+                ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64), ("max_lanes_per_read", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class SfaQueryInfo(C.Structure):

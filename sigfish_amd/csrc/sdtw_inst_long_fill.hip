@@ -1,0 +1,5 @@
+// sdtw_inst_long_fill.hip -- explicit instantiations (see sdtw_instances.hpp): queries of 513..2048 events
+#include "sdtw_kernels.hpp"
+namespace sfa {
+template __global__ void sdtw_fill_kernel<128, false, false>(const DpArgs);
+}  // namespace sfa

@@ -12,7 +12,9 @@
 // Mapping to the machine (MI355X-first, not a translation of the CPU loops):
 //   * one read occupies ONE DPP ROW (16 lanes) of a wave64; four reads ("a quad", equal query length) ride in
 //     a wave.  Lane g of a row owns R consecutive query rows (R = 4/8/16/32 -> queries up to 64/128/256/512
-//     events), kept in VGPRs together with their running cost.  No barriers, no cost matrix.
+//     events), kept in VGPRs together with their running cost.  No barriers, no cost matrix.  Queries longer
+//     than 512 events take 32 or 64 lanes per read at R = 32 (two reads / one read per wave, up to 1024 / 2048
+//     events); everything below is written for L lanes per read.
 //   * the lanes of a row walk an anti-diagonal: at step t lane g is at reference column t-g, so the only
 //     cross-lane traffic per step is ONE value per lane, the bottom cost handed to the next lane (through a
 //     wave-private LDS window, see Exchange): the neighbour's value from the previous step is this lane's "up",
@@ -37,9 +39,7 @@
 
 namespace sfa {
 
-constexpr int kLanesPerRead = 16;  // one DPP row
-constexpr int kReadsPerWave = 4;
-constexpr int kRefPad = 64;        // floats of padding on both sides of every (contig,strand) array in HBM
+constexpr int kRefPad = 128;       // floats of +inf padding on both sides of every (contig,strand) array in HBM (>= 64 lanes + 2 loads)
 #ifndef SFA_STEPS_PER_LOAD
 #define SFA_STEPS_PER_LOAD 4
 #endif
@@ -47,7 +47,7 @@ constexpr int kRefPad = 64;        // floats of padding on both sides of every (
 #define SFA_FILL_WAVES 6  // waves per SIMD the cost-only fill (R <= 16) is register-budgeted for: 80 VGPRs
 #endif
 constexpr int kStepsPerLoad = SFA_STEPS_PER_LOAD;  // reference levels fetched per load (4 = one 16-byte load)
-constexpr int kMaxClasses = 4;     // query-length classes R = 32, 16, 8, 4
+constexpr int kMaxClasses = 6;     // query-length classes (R, lanes) = (32,64) (32,32) (32,16) (16,16) (8,16) (4,16)
 
 struct __attribute__((packed, aligned(4))) float4u {
     float v[kStepsPerLoad];
@@ -56,7 +56,8 @@ struct __attribute__((packed, aligned(4))) float4u {
 // A query-length class inside one launch.
 struct ClassDesc {
     int32_t R;          // query rows per lane
-    int32_t quad_base;  // first quad
+    int32_t lanes;      // lanes per read: 16 (four reads per wave), 32 (two) or 64 (one)
+    int32_t quad_base;  // first quad (a "quad" is one wave's worth of reads: 64/lanes of them, slots 0..)
     int32_t n_quads;
     int32_t task_base;  // first task (fill: n_quads*n_chunks tasks, trace: n_quads tasks)
     int64_t ck_base;    // float offset of this class's checkpoint region
@@ -100,18 +101,18 @@ struct DpArgs {
 // through a wave-private LDS window instead: every lane stores its bottom value in word g+1 of its read's
 // window and loads word g; word 0 holds the boundary value for query row 0.  LDS operations of one
 // wave execute in order, the windows are private to the wave, hence no barrier; the LDS pipe is otherwise idle.
-// Bank-conflict-free layout (ds_*_b32: 32 banks, two 32-lane groups): read r's window is the 16 words
-// [16r, 16r+16): word 0 = boundary, lane g (< 15) stores to word g+1, every lane g loads word g.  Lane 15's value has
-// no reader; it goes to a private dummy word at 64+16r (banks 0/16, the two banks its group leaves free).
+// Bank-conflict-free layout (ds_*_b32: 32 banks, two 32-lane groups), L = lanes per read: read r's window is the
+// L words [L*r, L*r+L): word 0 = boundary, lane g (< L-1) stores to word g+1, every lane g loads word g.  The last
+// lane's value has no reader; it goes to a private dummy word at 64+L*r (the banks its 32-lane group leaves free).
 constexpr int kXchWordsPerWave = 128;
 
 struct Exchange {
     float *wf, *rf;  // this lane's store / load slot (bottom cost)
     int *wi, *ri;    // same for the bottom start column, TRACK only
-    __device__ __forceinline__ void init(float *lds_f, int *lds_i, int wave_in_block, int slot, int g) {
+    __device__ __forceinline__ void init(float *lds_f, int *lds_i, int wave_in_block, int slot, int g, int L) {
         const int base = wave_in_block * kXchWordsPerWave;
-        const int w = base + (g < kLanesPerRead - 1 ? slot * kLanesPerRead + g + 1 : 64 + 16 * slot);
-        const int r = base + slot * kLanesPerRead + g;
+        const int w = base + (g < L - 1 ? slot * L + g + 1 : 64 + L * slot);
+        const int r = base + slot * L + g;
         wf = lds_f + w;
         rf = lds_f + r;
         wi = lds_i + w;
@@ -387,14 +388,14 @@ __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp,
     }
 }
 
-template <int R, bool TRACK, bool STD>
+template <int R, int L, bool TRACK, bool STD>
 __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
     const int quad_local = task_local - chunk * cd.n_quads;
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
-    const int g = lane & (kLanesPerRead - 1);
-    const int slot = lane >> 4;
+    const int g = lane & (L - 1);
+    const int slot = lane / L;
     const bool lane0 = (g == 0);
 
     const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);
@@ -406,7 +407,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     float x[R];
     load_query_rows<R>(x, a, read, qlen, g);
     Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g);
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
 
     Top2<TRACK> top;
     top.init();
@@ -433,8 +434,9 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     }
 }
 
-// grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR bounds the classes compiled in,
-// so a batch without long queries does not pay the long variant's register budget.
+// grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR (query rows per 16 lanes: 4..32,
+// 64 = two DPP rows per read, 128 = a whole wave per read) bounds the classes compiled in, so a batch without
+// long queries does not pay the long variant's register budget.
 template <int MAXR, bool TRACK, bool STD>
 __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES : 1) sdtw_fill_kernel(const DpArgs a) {
     const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -446,18 +448,24 @@ __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES :
     const int tl = task - cd.task_base;
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
-    switch (cd.R) {
+    switch (cd.R * (cd.lanes >> 4)) {  // query rows per 16 lanes
+        case 128:
+            if constexpr (MAXR >= 128) fill_body<32, 64, TRACK, STD>(a, cd, tl, lds_f, lds_i);
+            break;
+        case 64:
+            if constexpr (MAXR >= 64) fill_body<32, 32, TRACK, STD>(a, cd, tl, lds_f, lds_i);
+            break;
         case 32:
-            if constexpr (MAXR >= 32) fill_body<32, TRACK, STD>(a, cd, tl, lds_f, lds_i);
+            if constexpr (MAXR >= 32) fill_body<32, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
         case 16:
-            if constexpr (MAXR >= 16) fill_body<16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
+            if constexpr (MAXR >= 16) fill_body<16, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
         case 8:
-            if constexpr (MAXR >= 8) fill_body<8, TRACK, STD>(a, cd, tl, lds_f, lds_i);
+            if constexpr (MAXR >= 8) fill_body<8, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
         default:
-            fill_body<4, TRACK, STD>(a, cd, tl, lds_f, lds_i);
+            fill_body<4, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
     }
 }
@@ -468,13 +476,13 @@ __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES :
 // ---------------------------------------------------------------------------------------------------------
 struct ResultRow;  // below
 
-template <int R, bool STD>
+template <int R, int L, bool STD>
 __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st, float *lds_f,
                                            int *lds_i) {
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
-    const int g = lane & (kLanesPerRead - 1);
-    const int slot = lane >> 4;
+    const int g = lane & (L - 1);
+    const int slot = lane / L;
     const bool lane0 = (g == 0);
 
     const int qlen = a.quad_qlen[quad];
@@ -485,7 +493,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     float x[R];
     load_query_rows<R>(x, a, read, qlen, g);
     Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g);
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
 
     int job = (read >= 0) ? a.w_job[read] : -1;
     const int ws = (read >= 0) ? a.w_end[read] : 0;  // first column of the winning window
@@ -543,15 +551,17 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
         xc.template set_boundary<true>(lane0, (STD && tb > 0) ? INFINITY : 0.0f);
         const int len = done ? 0 : (t_last - tb + 1);
         int maxlen = __builtin_amdgcn_readlane(len, 0);
-        maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
-        maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
-        maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
+        if (L <= 32) maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
+        if (L <= 16) {
+            maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
+            maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
+        }
         if (maxlen <= 0) break;
 
         // first cell of the window whose cost equals the winning score (= the first strict minimum the reference's
         // scan selects, src/sigfish.c:892-899), and the start column carried into it
         int cap_end = done ? 0 : -1, cap_st = -1;
-        const int tlim = rlen + 16;  // keep the loads of rows that are already done inside the padded array
+        const int tlim = rlen + 64;  // keep the loads of rows that are already done inside the padded array
         for (int tau0 = 0; tau0 < maxlen; tau0 += kStepsPerLoad) {
             const int tbl = min(tb + tau0, tlim);
             const float4u yv = *reinterpret_cast<const float4u *>(ybase + tbl);
@@ -567,7 +577,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
             }
             if ((__ballot(cap_end >= 0) & owner) == owner) break;  // every read of the quad has its cell
         }
-        const int src = (lane & 48) + lq;  // the lane that owns the last query row of this read
+        const int src = (lane & ~(L - 1)) + lq;  // the lane that owns the last query row of this read
         const int q_end = __shfl(cap_end, src), q_st = __shfl(cap_st, src);
         if (!done) {
             if ((q_end >= 0 && q_st >= 0) || k == 0) {
@@ -625,18 +635,24 @@ __global__ void __launch_bounds__(256) sdtw_trace_kernel(const DpArgs a, int32_t
     const int tl = task - cd.task_base;
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[4 * kXchWordsPerWave];
-    switch (cd.R) {
+    switch (cd.R * (cd.lanes >> 4)) {
+        case 128:
+            if constexpr (MAXR >= 128) trace_body<32, 64, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            break;
+        case 64:
+            if constexpr (MAXR >= 64) trace_body<32, 32, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            break;
         case 32:
-            if constexpr (MAXR >= 32) trace_body<32, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            if constexpr (MAXR >= 32) trace_body<32, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
         case 16:
-            if constexpr (MAXR >= 16) trace_body<16, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            if constexpr (MAXR >= 16) trace_body<16, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
         case 8:
-            if constexpr (MAXR >= 8) trace_body<8, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            if constexpr (MAXR >= 8) trace_body<8, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
         default:
-            trace_body<4, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            trace_body<4, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
     }
 }

@@ -151,7 +151,9 @@ void launch_fill(int maxr, bool std_dtw, const DpArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, true>), grid, block, 0, st, a);           \
     else                                                                                               \
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, false>), grid, block, 0, st, a)
-    if (maxr >= 32) {
+    if (maxr > 32) {
+        SFA_FILL(128);
+    } else if (maxr >= 32) {
         SFA_FILL(32);
     } else if (maxr >= 16) {
         SFA_FILL(16);
@@ -170,7 +172,9 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
         hipLaunchKernelGGL((sfa::sdtw_trace_kernel<MR, true>), grid, block, 0, st, a, out_st);         \
     else                                                                                               \
         hipLaunchKernelGGL((sfa::sdtw_trace_kernel<MR, false>), grid, block, 0, st, a, out_st)
-    if (maxr >= 32) {
+    if (maxr > 32) {
+        SFA_TRACE(128);
+    } else if (maxr >= 32) {
         SFA_TRACE(32);
     } else if (maxr >= 16) {
         SFA_TRACE(16);
@@ -252,6 +256,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.n_cls = static_cast<int32_t>(plan.classes.size());
     for (int i = 0; i < da.n_cls; ++i) {
         da.cls[i].R = plan.classes[i].R;
+        da.cls[i].lanes = plan.classes[i].lanes;
         da.cls[i].quad_base = plan.classes[i].quad_base;
         da.cls[i].n_quads = plan.classes[i].n_quads;
         da.cls[i].task_base = plan.classes[i].quad_base * n_chunks;  // classes are contiguous in quad order
@@ -286,9 +291,9 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (n_quads > 0) {
         if (plan.single_pass)
-            launch_fill<true>(plan.max_R, std_dtw, da, st);
+            launch_fill<true>(plan.max_span / 16, std_dtw, da, st);
         else
-            launch_fill<false>(plan.max_R, std_dtw, da, st);
+            launch_fill<false>(plan.max_span / 16, std_dtw, da, st);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));
@@ -300,7 +305,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         DpArgs ta = da;
         for (int i = 0; i < ta.n_cls; ++i) ta.cls[i].task_base = ta.cls[i].quad_base;  // one task per quad
         ta.n_tasks = n_quads;
-        launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
+        launch_trace(plan.max_span / 16, std_dtw, ta, c->d_tst.as<int32_t>(), st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[3], st));
         fz.mode = 2;

@@ -128,6 +128,8 @@ int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len
     info->trace_margin = plan.trace_margin;
     info->ckpt_bytes = plan.ck_floats * 4;
     info->n_tasks = static_cast<int64_t>(plan.n_quads) * plan.n_chunks;
+    info->max_lanes_per_read = plan.max_lanes;
+    info->reserved = 0;
     return SFA_OK;
 }
 

@@ -3,7 +3,8 @@
 // Replaces the reference's per-batch thread fan-out (work_db / pthread_db, src/thread.c:74-132: contiguous
 // read ranges per thread + work stealing) with a static plan for the GPU:
 //   * reads of EQUAL query length are grouped four at a time into "quads" (one wavefront each); lengths select
-//     a rows-per-lane class R (4/8/16/32) -- long classes first so that short work fills the tail;
+//     a rows-per-lane class R (4/8/16/32) -- long classes first so that short work fills the tail; queries of
+//     513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read per "quad";
 //   * the (contig,strand) job list is cut into contiguous chunks of similar size when there are too few quads
 //     to fill the chip; a wave-task is (quad, chunk);
 //   * the checkpoint interval T of pass 1 is the smallest power of two >= 1024 whose checkpoints fit the budget.
@@ -16,14 +17,19 @@
 
 namespace sfa {
 
-constexpr int kMaxQuery = 512;
+constexpr int kMaxQuery = 2048;
 
-inline int rows_per_lane_for(int qlen) {
-    if (qlen <= 64) return 4;
-    if (qlen <= 128) return 8;
-    if (qlen <= 256) return 16;
-    if (qlen <= 512) return 32;
-    return 0;
+struct ClassShape {
+    int R, lanes;  // query rows per lane, lanes per read: the class holds queries of up to R*lanes events
+};
+// classes in task order (long first)
+constexpr ClassShape kClassShapes[6] = {{32, 64}, {32, 32}, {32, 16}, {16, 16}, {8, 16}, {4, 16}};
+
+inline int class_for(int qlen) {  // index into kClassShapes, -1: too long
+    if (qlen > kMaxQuery) return -1;
+    int c = 0;
+    while (c + 1 < 6 && qlen <= kClassShapes[c + 1].R * kClassShapes[c + 1].lanes) ++c;
+    return c;
 }
 
 // checkpoints the fill stores for a job of rlen columns at interval 1<<shift: k*T <= rlen-4 (a block boundary at or
@@ -36,16 +42,16 @@ struct PlanParams {
     bool single_pass = false;
     int64_t ckpt_interval = 0;      // 0 = auto
     int64_t ckpt_budget_bytes = 8ll << 30;
-    int64_t trace_margin = -1;      // -1 = longest query + 16
+    int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
 };
 
 struct PlanClass {
-    int R = 0, quad_base = 0, n_quads = 0;
+    int R = 0, lanes = 16, quad_base = 0, n_quads = 0;
     int64_t ck_base = 0;  // float offset
 };
 
 struct BatchPlan {
-    int32_t n_quads = 0, n_chunks = 1, max_R = 4, ck_shift = 0, trace_margin = 0;
+    int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, max_span = 64, ck_shift = 0, trace_margin = 0;
     bool single_pass = false;
     int64_t ck_floats = 0, query_events = 0;
     std::vector<int32_t> order;         // [4*max(n_quads,1)] read per (quad,slot) or -1
@@ -95,23 +101,27 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     }
     std::vector<int32_t> count(maxq + 2, 0);
     for (int32_t i = 0; i < n; ++i) count[qlen[i]]++;
-    // classes in task order: R = 32, 16, 8, 4 (long first); inside a class by descending length
+    // classes in task order (long first); inside a class by descending length
     std::vector<int32_t> quad_start(maxq + 2, -1);
     int32_t n_quads = 0;
-    for (int R : {32, 16, 8, 4}) {
+    for (int ci = 0; ci < 6; ++ci) {
         PlanClass cl;
-        cl.R = R;
+        cl.R = kClassShapes[ci].R;
+        cl.lanes = kClassShapes[ci].lanes;
         cl.quad_base = n_quads;
+        const int per = 64 / cl.lanes;  // reads per wave
         for (int l = maxq; l >= 1; --l) {
-            if (count[l] == 0 || rows_per_lane_for(l) != R) continue;
+            if (count[l] == 0 || class_for(l) != ci) continue;
             quad_start[l] = n_quads;
-            n_quads += (count[l] + 3) / 4;
+            n_quads += (count[l] + per - 1) / per;
         }
         cl.n_quads = n_quads - cl.quad_base;
         if (cl.n_quads > 0) p.classes.push_back(cl);
     }
     p.n_quads = n_quads;
     p.max_R = p.classes.empty() ? 4 : p.classes.front().R;
+    p.max_lanes = p.classes.empty() ? 16 : p.classes.front().lanes;
+    p.max_span = p.max_R * p.max_lanes;
     p.order.assign(4 * static_cast<size_t>(std::max(n_quads, 1)), -1);
     p.quad_qlen.assign(std::max(n_quads, 1), 1);
     p.slot_of_read.assign(n, -1);
@@ -120,13 +130,16 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         const int l = qlen[i];
         if (l == 0) continue;
         const int32_t k = fill_pos[l]++;
-        const int32_t sl = (quad_start[l] + (k >> 2)) * 4 + (k & 3);
+        const int per = 64 / kClassShapes[class_for(l)].lanes;
+        const int32_t sl = (quad_start[l] + k / per) * 4 + (k % per);  // a wave always has four slots; long classes use 2 / 1
         p.order[sl] = i;
         p.slot_of_read[i] = sl;
     }
     for (int l = 1; l <= maxq; ++l)
-        if (count[l])
-            for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + 3) / 4; ++qd) p.quad_qlen[qd] = l;
+        if (count[l]) {
+            const int per = 64 / kClassShapes[class_for(l)].lanes;
+            for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + per - 1) / per; ++qd) p.quad_qlen[qd] = l;
+        }
 
     // chunk the job list only as far as needed to fill the machine
     p.n_chunks = 1;
@@ -140,7 +153,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
 
     // checkpoint interval
     p.job_ck_off.assign(n_jobs + 1, 0);
-    p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + 16);
+    p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + p.max_lanes);
     if (!pp.single_pass && n_quads > 0) {
         int shift = 10;
         if (pp.ckpt_interval > 0) {

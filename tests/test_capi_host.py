@@ -116,8 +116,34 @@ def test_plan_batch_layout():
     # few reads, many contigs: the contig list is chunked to fill the machine
     info3, _ = plan_batch(np.array([0, 250, 500], np.int64), [375] * 160)
     assert info3["n_quads"] == 1 and info3["n_chunks"] == 160
+    assert info["max_lanes_per_read"] == 16
     with pytest.raises(S.SfaError):
-        plan_batch(np.array([0, 600], np.int64), [100])
+        plan_batch(np.array([0, 2049], np.int64), [100])  # > SFA_MAX_QUERY
+
+
+def test_plan_batch_long_queries():
+    """Queries of 513..1024 / 1025..2048 events take 32 / 64 lanes: two reads / one read per wave."""
+    from sigfish_amd.api import plan_batch
+    lens = np.array([2048, 1025, 1025, 1024, 1024, 1024, 513, 512, 512, 250, 250, 250, 250, 250, 600, 600])
+    q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    info, slot = plan_batch(q_off, [5000])
+    assert info["max_lanes_per_read"] == 64 and info["max_rows_per_lane"] == 32 and info["n_classes"] == 4
+    assert info["trace_margin"] == 2048 + 64
+    quad, sl = slot >> 2, slot & 3
+    assert len(np.unique(slot)) == len(slot)
+    assert (sl[lens > 1024] == 0).all()                        # a wave to itself
+    assert (sl[(lens > 512) & (lens <= 1024)] <= 1).all()      # two per wave
+    for qd in np.unique(quad):
+        assert len(set(lens[quad == qd])) == 1
+    # waves: 2048 -> 1, 1025 x2 -> 2, 1024 x3 -> 2, 600 x2 -> 1, 513 -> 1, 512 x2 -> 1, 250 x5 -> 2
+    assert info["n_quads"] == 10
+    # long classes first
+    order = np.argsort(slot)
+    span = np.select([lens[order] <= 64, lens[order] <= 128, lens[order] <= 256, lens[order] <= 512, lens[order] <= 1024],
+                     [64, 128, 256, 512, 1024], 2048)
+    assert (np.diff(span) <= 0).all()
+    info2, _ = plan_batch(np.array([0, 700], np.int64), [100])
+    assert info2["max_lanes_per_read"] == 32 and info2["trace_margin"] == 700 + 32
 
 
 def test_plan_batch_empty_and_single():

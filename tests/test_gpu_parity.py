@@ -112,6 +112,47 @@ def test_ragged_and_ties(oracle, seed, mode, gpu_mode):
     assert_rows_equal(got, want)
 
 
+@pytest.mark.parametrize("gpu_mode", list(MODES))
+@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
+def test_long_queries(oracle, seed, mode, gpu_mode):
+    """`-q` beyond 512 events: 32 lanes per read up to 1024 events, a whole wave per read up to 2048, mixed in one
+    batch with the ordinary classes; contigs shorter than the query included."""
+    rng = np.random.default_rng(7000 + seed)
+    rna = mode != "dna"
+    flag = {"dna": 0, "rna": S.RNA, "rna_std": S.RNA | S.DTW, "rna_inv": S.RNA | S.INV}[mode]
+    quant = seed == 1
+    lens = [int(x) for x in rng.integers(600, 6000, size=int(rng.integers(1, 5)))] + [int(rng.integers(3, 500))]
+    ref = _small_ref(rng, lens, rna, quant)
+    qlens = rng.choice([0, 64, 250, 512, 513, 600, 1000, 1023, 1024, 1025, 1500, 2047, 2048], size=int(rng.integers(3, 20)))
+    qlens[0] = [2048, 1024, 1025][seed]
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = (rng.integers(-6, 7, int(q_off[-1])) / 4).astype(np.float32) if quant else rng.normal(size=int(q_off[-1])).astype(np.float32)
+    with _aligner(ref, flag, gpu_mode) as al:
+        got = al.align_db(q, q_off)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=8)
+    assert_rows_equal(got, want)
+
+
+def test_long_queries_ncov(oracle):
+    """q = 1000 and 2000 against the nCoV reference (both strands), default checkpointing."""
+    ref, flag, q250, off250, meta = synth.workload("ncov_r9_dna_q250", n_reads=8, seed=11)
+    rng = np.random.default_rng(12)
+    qlens = np.array([1000, 2000, 1000, 700, 250, 2000, 1000])
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = np.empty(int(q_off[-1]), np.float32)
+    fw = ref.forward[0]
+    for i, l in enumerate(qlens):  # noisy copies of reference stretches, so that real alignments exist
+        st = int(rng.integers(0, len(fw) - l))
+        seg = fw[st:st + l] + rng.normal(scale=0.3, size=l).astype(np.float32)
+        q[q_off[i]:q_off[i + 1]] = ((seg - seg.mean()) / seg.std()).astype(np.float32)
+    with S.Aligner(ref, flag) as al:
+        got = al.align_db(q, q_off)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16)
+    assert_rows_equal(got, want)
+    assert (got["mapq"][[0, 1, 2, 5, 6]] > 0).all()
+
+
 @pytest.mark.parametrize("interval,margin", [(4, 0), (8, 3), (64, 0), (256, 100), (1024, -1)])
 def test_checkpoint_intervals(oracle, interval, margin):
     """Pass 2 must recover the same start column from any checkpoint spacing, including the back-off path
@@ -238,4 +279,4 @@ def test_no_device_fallback_is_loud():
         S.Aligner(ref, 0, device=99)
     with S.Aligner(ref, 0) as al:
         with pytest.raises(S.SfaError):
-            al.align_db(np.zeros(600, np.float32), np.array([0, 600], np.int64))  # > SFA_MAX_QUERY
+            al.align_db(np.zeros(2049, np.float32), np.array([0, 2049], np.int64))  # > SFA_MAX_QUERY
