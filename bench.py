@@ -22,6 +22,7 @@ The JSON line also carries
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -52,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step (default 100 000 at -q 250, same cell count otherwise)")
     ap.add_argument("--workload", default="ncov_r9_dna_q250")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,7 +93,10 @@ def main():
         al.set_option(k, int(v))
 
     # ---- this rank's shard of reads: synthetic, generated here, uploaded to HBM before the timed region ----
-    q, q_off, _ = synth.make_reads(ref, args.reads, qlen=250, seed=1000 + rank)
+    qlen = int(re.search(r"_q(\d+)$", args.workload).group(1))  # every workload name ends in its -q value
+    if args.reads is None:
+        args.reads = 100_000 * 250 // qlen
+    q, q_off, _ = synth.make_reads(ref, args.reads, qlen=qlen, seed=1000 + rank)
     n = args.reads
     lens = q_off[1:] - q_off[:-1]
     strands = 1 if ref.reverse is None else 2
@@ -150,7 +154,7 @@ def main():
     # HBM bytes per fill launch from the committed PMC passes of this build (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     # KB -> bytes; MI355X_MICROARCH.md section HBM).  Only quoted for the configuration that was profiled.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_v5_pmc_summary.csv")
+    pmc = os.path.join(ROOT, "profiles", "r01_v7_pmc_summary.csv")
     if os.path.exists(pmc) and args.workload == "ncov_r9_dna_q250" and n == 100_000 and not args.opt:
         vals = {}
         for line in open(pmc).read().splitlines()[1:]:
@@ -159,9 +163,10 @@ def main():
                 vals[counter] = float(mean)
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            traffic_src = "profiles/r01_v5_pmc_summary.csv (separate rocprofv3 --pmc passes of this build, same workload)"
+            traffic_src = "profiles/r01_v7_pmc_summary.csv (separate rocprofv3 --pmc passes of this build, same workload)"
     out = {
-        "metric": "reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)",
+        "metric": ("reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)" if args.workload == "ncov_r9_dna_q250"
+                   else f"reads/s (sDTW alignment stage: {args.workload})"),
         "value": round(value, 1),
         "unit": "reads/s",
         "n_gpus": world,
@@ -173,8 +178,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": args.workload, "reads_per_gpu": n, "query_events": 250, "ref_kmers": int(ref.ref_lengths.sum()),
-                   "strands": strands, "sharding": f"reads x{world}", "cells_per_read_full": 250 * cols},
+        "config": {"workload": args.workload, "reads_per_gpu": n, "query_events": qlen, "ref_kmers": int(ref.ref_lengths.sum()),
+                   "strands": strands, "sharding": f"reads x{world}", "cells_per_read_full": qlen * cols},
         "dp_cells_per_s": round(cells * world * args.steps / elapsed, 1),
         "roofline": {
             "bound": "hbm", "kernel": "sdtw_fill_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -86,10 +86,13 @@ def workload(name, n_reads=None, seed=0, golden_dir=None):
     """The BASELINE.json configurations as (RefModel, flag, queries, q_off, meta)."""
     import os
     gd = golden_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-    if name == "ncov_r9_dna_q250":  # configs[2]: synthetic R9 DNA reads x 30 kb nCoV reference, -q 250
+    import re
+    m = re.fullmatch(r"ncov_r9_dna_q(\d+)", name)
+    if m:  # q250 = configs[2]: synthetic R9 DNA reads x 30 kb nCoV reference, -q 250; other -q values for the long classes
         lv = kmer_levels(6, 1)
-        ref = api.RefModel.from_fasta(os.path.join(gd, "data", "nCoV-2019.reference.fasta"), lv, 6, 0, 250)
-        flag, qlen, n = 0, 250, n_reads or 100_000
+        qlen = int(m.group(1))
+        ref = api.RefModel.from_fasta(os.path.join(gd, "data", "nCoV-2019.reference.fasta"), lv, 6, 0, qlen)
+        flag, n = 0, n_reads or 100_000 * 250 // qlen
     elif name == "r10_dna_1mb_q250":  # configs[3]: synthetic R10 DNA reads x 1 Mb reference (k=9)
         lv = kmer_levels(9, 3)
         ref = api.RefModel.from_records([("synthetic_1Mb", random_sequence(1_000_000, 4))], lv, 9, 0, 250)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""summarise_profiles.py <dir> <tag>: condense the rocprofv3 output of tools/profile_round.sh into the two small
+CSVs kept under profiles/: <tag>_kernel_stats.csv (copy of the --stats table) and <tag>_pmc_summary.csv
+(per kernel and counter: dispatches, mean value per dispatch, mean kernel duration inside that pass).  The first
+dispatch of every kernel (warm-up step) is dropped from the PMC means."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+
+def short(name):
+    return name.split("(")[0].strip()
+
+
+def main(d, tag):
+    ks = glob.glob(os.path.join(d, "kt", "**", "*_kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copyfile(ks[0], os.path.join(d, f"{tag}_kernel_stats.csv"))
+    rows = []
+    for name in ("fetch", "write", "sq", "grbm"):
+        cc = glob.glob(os.path.join(d, name, "**", "*_counter_collection.csv"), recursive=True)
+        if not cc:
+            continue
+        per = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> dispatch -> (val, dur)
+        with open(cc[0]) as f:
+            for r in csv.DictReader(f):
+                k = short(r["Kernel_Name"])
+                if "sfa::" not in k:
+                    continue
+                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                slot = per[k][r["Counter_Name"]]
+                did = int(r["Dispatch_Id"])
+                v, _ = slot.get(did, (0.0, dur))
+                slot[did] = (v + float(r["Counter_Value"]), dur)  # rows of one dispatch (per XCD / dimension) add up
+        for k in sorted(per):
+            for c in sorted(per[k]):
+                ds = sorted(per[k][c])
+                keep = ds[len(ds) // 4:] if len(ds) >= 4 else ds  # drop the warm-up step's dispatches
+                vals = [per[k][c][i][0] for i in keep]
+                durs = [per[k][c][i][1] for i in keep]
+                rows.append((k, c, len(keep), sum(vals) / len(vals), sum(durs) / len(durs)))
+    with open(os.path.join(d, f"{tag}_pmc_summary.csv"), "w") as f:
+        f.write("kernel,counter,dispatches,mean_value_per_dispatch,mean_duration_ms_in_that_pass\n")
+        for k, c, n, v, t in rows:
+            f.write(f'"{k}",{c},{n},{v:.1f},{t:.3f}\n')
+    print(open(os.path.join(d, f"{tag}_pmc_summary.csv")).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
