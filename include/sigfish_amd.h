@@ -120,6 +120,14 @@ int sfa_align_batch(sfa_ctx_t *ctx, const float *queries, const int64_t *q_off, 
 int sfa_align_batch_device(sfa_ctx_t *ctx, const float *d_queries, const int64_t *q_off, int32_t n_reads,
                            sfa_result_t *d_out, int sync);
 
+/* The same call split in two, so that the host can load and event-detect batch i+1 while batch i is on the GPU
+ * (the overlap the reference's strictly serial load -> process -> output loop, src/dtw_main.c:299-326, lacks).
+ * sfa_submit_batch returns once the work is queued; `queries` must stay valid until sfa_wait_batch, which blocks,
+ * fills out[n_reads] and must be called with the same n_reads.  One batch in flight per context: a second submit
+ * waits for the first to finish and discards its rows.  sfa_align_batch == submit + wait. */
+int sfa_submit_batch(sfa_ctx_t *ctx, const float *queries, const int64_t *q_off, int32_t n_reads);
+int sfa_wait_batch(sfa_ctx_t *ctx, sfa_result_t *out, int32_t n_reads);
+
 /* align_db() shaped entry: per-read event tables exactly as db_t holds them (src/sigfish.h:177-178):
  * events[i] -> sfa_event_t array of read i, qstart[i]/qend[i] the window chosen by normalise_single
  * (src/sigfish.c:479-480); reads with n_events[i]==0 are skipped. */

@@ -164,6 +164,26 @@ class Aligner:
                                        out.ctypes.data_as(C.c_void_p)), "sfa_align_batch")
         return out
 
+    def submit(self, queries, q_off):
+        """First half of align_db: queue the batch and return; collect the rows with wait().  One batch in flight."""
+        q = _f32(queries)
+        qo = np.ascontiguousarray(q_off, np.int64)
+        if q.size == 0:
+            q = np.zeros(1, np.float32)
+        self._pending = (q, qo)  # the library reads `queries` until wait()
+        _check(self._L.sfa_submit_batch(self._h, q.ctypes.data_as(_lib.f32p), qo.ctypes.data_as(_lib.i64p), len(qo) - 1),
+               "sfa_submit_batch")
+
+    def wait(self):
+        q, qo = getattr(self, "_pending", None) or (None, np.zeros(1, np.int64))
+        n = len(qo) - 1
+        out = np.zeros(n, RESULT_DTYPE)
+        try:
+            _check(self._L.sfa_wait_batch(self._h, out.ctypes.data_as(C.c_void_p), n), "sfa_wait_batch")
+        finally:
+            self._pending = None
+        return out
+
     # -- same with device-resident buffers (torch tensors or raw pointers) ------------------------------------
     def align_db_device(self, d_queries_ptr, q_off, n, d_out_ptr, sync=True):
         qo = np.ascontiguousarray(q_off, np.int64)

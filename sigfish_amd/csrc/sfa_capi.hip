@@ -133,6 +133,7 @@ struct sfa_ctx {
 
     sfa_profile_t prof{};
     bool prof_pending = false;
+    int32_t pending_n = -1;  // reads of the batch submitted with sfa_submit_batch and not yet collected
 };
 
 namespace {
@@ -482,11 +483,15 @@ int sfa_align_batch_device(sfa_ctx_t *c, const float *d_queries, const int64_t *
     return SFA_OK;
 }
 
-int sfa_align_batch(sfa_ctx_t *c, const float *queries, const int64_t *q_off, int32_t n, sfa_result_t *out) {
-    if (!c || !q_off || n < 0 || (n > 0 && (!queries || !out))) return fail(SFA_EINVAL, "sfa_align_batch: bad argument");
-    if (n == 0) return SFA_OK;
+int sfa_submit_batch(sfa_ctx_t *c, const float *queries, const int64_t *q_off, int32_t n) {
+    if (!c || !q_off || n < 0 || (n > 0 && !queries)) return fail(SFA_EINVAL, "sfa_submit_batch: bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // one batch in flight per context
+    c->pending_n = -1;
+    if (n == 0) {
+        c->pending_n = 0;
+        return SFA_OK;
+    }
     const int64_t nq = q_off[n] - q_off[0];
     if (nq < 0) return fail(SFA_EINVAL, "q_off not monotone");
     int rc;
@@ -504,9 +509,26 @@ int sfa_align_batch(sfa_ctx_t *c, const float *queries, const int64_t *q_off, in
     HIP_TRY(hipMemcpyAsync(c->d_queries.p, queries + q_off[0], sizeof(float) * nq, hipMemcpyHostToDevice, c->stream));
     if ((rc = align_device(c, c->d_queries.as<float>(), qo, n, c->d_out.as<ResultRow>()))) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_out.p, sizeof(sfa_result_t) * n, hipMemcpyDeviceToHost, c->stream));
+    c->pending_n = n;
+    return SFA_OK;
+}
+
+int sfa_wait_batch(sfa_ctx_t *c, sfa_result_t *out, int32_t n) {
+    if (!c || n < 0 || (n > 0 && !out)) return fail(SFA_EINVAL, "sfa_wait_batch: bad argument");
+    if (c->pending_n < 0) return fail(SFA_EINVAL, "sfa_wait_batch: no batch was submitted");
+    if (c->pending_n != n) return fail(SFA_EINVAL, "sfa_wait_batch: %d reads were submitted, %d asked for", c->pending_n, n);
+    c->pending_n = -1;
+    if (n == 0) return SFA_OK;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_out.p, sizeof(sfa_result_t) * n);
     return resolve_profile(c);
+}
+
+int sfa_align_batch(sfa_ctx_t *c, const float *queries, const int64_t *q_off, int32_t n, sfa_result_t *out) {
+    if (!c || !q_off || n < 0 || (n > 0 && (!queries || !out))) return fail(SFA_EINVAL, "sfa_align_batch: bad argument");
+    if (int rc = sfa_submit_batch(c, queries, q_off, n)) return rc;
+    return sfa_wait_batch(c, out, n);
 }
 
 int sfa_align_events(sfa_ctx_t *c, const sfa_event_t *const *events, const int64_t *n_events, const int64_t *qstart,

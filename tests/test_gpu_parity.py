@@ -205,6 +205,32 @@ def test_many_batches_reuse_context(oracle):
             assert got.tobytes() == want[lo:hi].tobytes()
 
 
+def test_submit_wait_pair(oracle):
+    """sfa_submit_batch / sfa_wait_batch: the asynchronous half-calls return the rows of the synchronous call."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=64, seed=21)
+    with S.Aligner(ref, flag) as al:
+        want = al.align_db(q, q_off)
+        al.submit(q, q_off)
+        host_work = np.cumsum(np.arange(100000))  # anything: the batch is on the GPU meanwhile
+        got = al.wait()
+        assert got.tobytes() == want.tobytes() and host_work[-1] > 0
+        with pytest.raises(S.SfaError, match="no batch"):
+            al.wait()
+        # a second submit before wait discards the first batch
+        al.submit(q[:q_off[8]], q_off[:9])
+        al.submit(q, q_off)
+        assert al.wait().tobytes() == want.tobytes()
+        # mismatched size
+        al.submit(q, q_off)
+        out = np.zeros(3, S.api.RESULT_DTYPE)
+        import ctypes as C
+        assert al._L.sfa_wait_batch(al._h, out.ctypes.data_as(C.c_void_p), 3) != 0
+        # empty batch
+        al.submit(np.zeros(0, np.float32), np.zeros(1, np.int64))
+        assert len(al.wait()) == 0
+    assert_rows_equal(want, oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=8))
+
+
 def test_align_events_entry(oracle):
     """align_db-shaped entry: AoS event tables + qstart/qend, as db_t holds them."""
     from sigfish_amd.api import EVENT_DTYPE
