@@ -113,7 +113,7 @@ struct sfa_ctx {
     // tunables (sfa_set_option)
     int64_t opt_single_pass = 0;             // 1: one fill with start tracking everywhere (first-round design)
     int64_t opt_ckpt_interval = 0;           // force the checkpoint interval (power of two >= 4); 0 = auto
-    int64_t opt_ckpt_budget = 8ll << 30;     // bytes of HBM the checkpoints of one batch may take
+    int64_t opt_ckpt_budget = 32ll << 30;    // bytes of HBM the checkpoints of one batch may take
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
 

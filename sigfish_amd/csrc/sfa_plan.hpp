@@ -7,7 +7,7 @@
 //     513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read per "quad";
 //   * the (contig,strand) job list is cut into contiguous chunks of similar size when there are too few quads
 //     to fill the chip; a wave-task is (quad, chunk);
-//   * the checkpoint interval T of pass 1 is the smallest power of two >= 1024 whose checkpoints fit the budget.
+//   * the checkpoint interval T of pass 1 is the smallest power of two >= 512 whose checkpoints fit the budget.
 #pragma once
 
 #include <algorithm>
@@ -41,7 +41,7 @@ struct PlanParams {
     int64_t waves_per_simd = 6;     // occupancy to aim for when chunking
     bool single_pass = false;
     int64_t ckpt_interval = 0;      // 0 = auto
-    int64_t ckpt_budget_bytes = 8ll << 30;
+    int64_t ckpt_budget_bytes = 32ll << 30;
     int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
 };
 
@@ -155,7 +155,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     p.job_ck_off.assign(n_jobs + 1, 0);
     p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + p.max_lanes);
     if (!pp.single_pass && n_quads > 0) {
-        int shift = 10;
+        int shift = 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length)
         if (pp.ckpt_interval > 0) {
             shift = 0;
             while ((1ll << shift) < pp.ckpt_interval) ++shift;

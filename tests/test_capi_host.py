@@ -104,7 +104,7 @@ def test_plan_batch_layout():
     assert info["n_quads"] == len(np.unique(quads))
     assert info["n_classes"] == 4 and info["max_rows_per_lane"] == 32
     assert 1 <= info["n_chunks"] <= 2 and info["n_tasks"] == info["n_quads"] * info["n_chunks"]
-    assert info["ckpt_interval"] == 1024 and info["trace_margin"] == 512 + 16
+    assert info["ckpt_interval"] == 512 and info["trace_margin"] == 512 + 16
     # long classes come first in task order
     order = np.argsort(used)
     l_sorted = lens[lens > 0][order]
@@ -112,7 +112,7 @@ def test_plan_batch_layout():
     assert (np.diff(rpl) <= 0).all()
     # a tight budget raises the interval instead of failing
     info2, _ = plan_batch(q_off, [29898, 29898], ckpt_budget_bytes=1 << 20)
-    assert info2["ckpt_interval"] > 1024 and info2["ckpt_bytes"] <= 1 << 20
+    assert info2["ckpt_interval"] > 512 and info2["ckpt_bytes"] <= 1 << 20
     # few reads, many contigs: the contig list is chunked to fill the machine
     info3, _ = plan_batch(np.array([0, 250, 500], np.int64), [375] * 160)
     assert info3["n_quads"] == 1 and info3["n_chunks"] == 160

@@ -176,7 +176,7 @@ def test_checkpoint_budget_picks_larger_interval():
         al.set_option("ckpt_budget_bytes", 64 * 1024)
         b = al.align_db(q, q_off)
         pb = al.profile()
-    assert pa["ckpt_interval"] == 1024 and pb["ckpt_interval"] > 1024 and pb["ckpt_bytes"] <= 64 * 1024
+    assert pa["ckpt_interval"] == 512 and pb["ckpt_interval"] > 512 and pb["ckpt_bytes"] <= 64 * 1024
     assert a.tobytes() == b.tobytes()
 
 
