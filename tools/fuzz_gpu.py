@@ -25,7 +25,7 @@ def main():
         flag = {"dna": 0, "rna": S.RNA, "rna_std": S.RNA | S.DTW, "rna_inv": S.RNA | S.INV}[mode]
         quant = bool(rng.integers(0, 2))
         nref = int(rng.integers(1, 13))
-        lens = [int(x) for x in rng.choice([1, 2, 3, 5, 17, 64, 250, 251, 500, 999, 1024, 1500, 3000], size=nref)]
+        lens = [int(x) for x in rng.choice([1, 2, 3, 5, 17, 64, 250, 251, 500, 999, 1024, 1500, 3000, 5000], size=nref)]
 
         def arr(n):
             return (rng.integers(-8, 9, n) / 4).astype(np.float32) if quant else rng.normal(size=n).astype(np.float32)
@@ -33,7 +33,9 @@ def main():
         rv = None if rna else [arr(n) for n in lens]
         ref = S.RefModel([f"c{i}" for i in range(nref)], [n + 5 for n in lens], lens, rng.integers(0, 4, nref) if rna else [0] * nref, fw, rv)
         n = int(rng.integers(1, 70))
-        qmax = int(rng.choice([30, 64, 128, 250, 256, 512]))
+        qmax = int(rng.choice([30, 64, 128, 250, 256, 512, 512, 700, 1024, 1100, 2048]))
+        if qmax > 512:
+            n = min(n, 24)  # keeps the oracle's matrices (one per thread) small
         qlens = rng.integers(0, qmax + 1, size=n)
         if rng.integers(0, 3) == 0:
             qlens[:] = qmax
