@@ -101,8 +101,8 @@ typedef struct {
     int32_t trace_margin;
     int64_t ckpt_bytes;
     int64_t n_tasks;
-    int32_t max_lanes_per_read; /* 16, or 32 / 64 when queries longer than 512 / 1024 events are present */
-    int32_t reserved;
+    int32_t max_lanes_per_read; /* 16; 32 / 64 for queries longer than 512 / 1024 events or under lane widening */
+    int32_t lane_widening;      /* 1, 2 or 4: small batches trade rows per lane for lanes per read */
 } sfa_plan_info_t;
 
 /* Create a context on HIP device `device`, copy the reference event arrays into HBM.
@@ -136,14 +136,17 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
 
 /* Tuning knobs (all optional): "single_pass" (0/1: track start columns in one pass instead of fill + trace),
  * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = qlen+16),
- * "waves_per_simd" (1..8, occupancy target used when splitting the contig list). */
+ * "waves_per_simd" (1..8, occupancy target used when splitting the contig list), "lane_widening" (0 = auto by batch
+ * size, 1/2/4 = fixed: rows per lane / w and lanes per read * w, the small-batch latency shapes), "widen_below"
+ * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 2). */
 int sfa_set_option(sfa_ctx_t *ctx, const char *key, int64_t value);
 
 /* Plan a batch without running it: how reads would be grouped.  slot_of_read[n_reads] (may be NULL) receives
  * quad*4+slot per read or -1 for skipped reads; job_len[n_jobs] are the (contig,strand) lengths in processing
- * order.  ckpt_interval / ckpt_budget_bytes as in sfa_set_option (0 = defaults). */
+ * order.  ckpt_interval / ckpt_budget_bytes / lane_widening as in sfa_set_option (0 = defaults; the device is
+ * assumed to have 1024 SIMDs). */
 int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len, int32_t n_jobs, int64_t ckpt_interval,
-                   int64_t ckpt_budget_bytes, int32_t *slot_of_read, sfa_plan_info_t *info);
+                   int64_t ckpt_budget_bytes, int32_t lane_widening, int32_t *slot_of_read, sfa_plan_info_t *info);
 
 /* Block until everything enqueued on the context stream has finished. */
 int sfa_sync(sfa_ctx_t *ctx);

@@ -32,7 +32,7 @@ class SfaPlanInfo(C.Structure):
     _fields_ = [("n_quads", C.c_int32), ("n_chunks", C.c_int32), ("n_classes", C.c_int32),
                 ("max_rows_per_lane", C.c_int32), ("ckpt_interval", C.c_int32), ("trace_margin", C.c_int32),
                 ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64), ("max_lanes_per_read", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("lane_widening", C.c_int32)]
 
 
 class SfaQueryInfo(C.Structure):
@@ -75,7 +75,7 @@ def load():
     L.sfa_pinned_free.argtypes = [vp]
     L.sfa_pinned_free.restype = None
     L.sfa_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
-    L.sfa_plan_batch.argtypes = [i64p, C.c_int32, i32p, C.c_int32, C.c_int64, C.c_int64, i32p, C.POINTER(SfaPlanInfo)]
+    L.sfa_plan_batch.argtypes = [i64p, C.c_int32, i32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, i32p, C.POINTER(SfaPlanInfo)]
     L.sfa_sync.argtypes = [vp]
     L.sfa_get_profile.argtypes = [vp, C.POINTER(SfaProfile)]
     L.sfa_stream.argtypes = [vp]

@@ -244,7 +244,7 @@ class Aligner:
         return self._L.sfa_stream(self._h)
 
 
-def plan_batch(q_off, job_len, ckpt_interval=0, ckpt_budget_bytes=0):
+def plan_batch(q_off, job_len, ckpt_interval=0, ckpt_budget_bytes=0, lane_widening=0):
     """Host-side batch layout (no GPU needed): (info dict, slot_of_read int32[n])."""
     qo = np.ascontiguousarray(q_off, np.int64)
     jl = np.ascontiguousarray(job_len, np.int32)
@@ -252,7 +252,8 @@ def plan_batch(q_off, job_len, ckpt_interval=0, ckpt_budget_bytes=0):
     slot = np.zeros(max(n, 1), np.int32)
     info = _lib.SfaPlanInfo()
     _check(_lib.load().sfa_plan_batch(qo.ctypes.data_as(_lib.i64p), n, jl.ctypes.data_as(_lib.i32p), len(jl),
-                                      int(ckpt_interval), int(ckpt_budget_bytes), slot.ctypes.data_as(_lib.i32p),
+                                      int(ckpt_interval), int(ckpt_budget_bytes), int(lane_widening),
+                                      slot.ctypes.data_as(_lib.i32p),
                                       C.byref(info)), "sfa_plan_batch")
     return {k: getattr(info, k) for k, _ in _lib.SfaPlanInfo._fields_}, slot[:n]
 

@@ -8,9 +8,11 @@
 //
 // Bit-exactness dictates the parallelisation: the prefix sums are SEQUENTIAL double additions (a parallel scan
 // would round differently), and the peak picker is a data-dependent state machine.  So those two run one READ PER
-// LANE (64 reads per wave, thousands of reads in flight); only the t-statistic is data parallel (one block per
-// read, one sample per thread).  The work is tiny next to the DTW (a few ms per 100 k reads), so the strided
-// access of the lane-per-read kernels is acceptable.
+// LANE (64 reads per wave).  What a lane-per-read loop must not do is touch HBM itself (64 lanes, 64 different
+// reads: every access its own cache line, every iteration a memory round trip).  Both kernels therefore stage
+// TILES of 64 reads x 32 samples through LDS: the wave loads a tile with coalesced accesses (half a wave per read),
+// every lane then runs its sequential recurrence over its row of the tile out of LDS, and results leave the same
+// way.  The t-statistic and the event statistics are data parallel (one block per read).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -34,24 +36,99 @@ struct EvArgs {
     float thr1, thr2, peak_height;
 };
 
+constexpr int kEvTile = 32;  // samples per read staged per round (one half-wave covers one read's slice)
+
+// The 64 reads of a wave, as every lane needs them in the cooperative phases: iteration `it` of a half-wave touches
+// read r = 2*it + half, and the lane keeps that read's offset (relative to the wave's first read, 32 bits) and length
+// in registers -- the inner loops then cost one add, one compare and the access itself.
+struct TileReads {
+    uint32_t rel[32];
+    int32_t len[32];
+    int64_t b0;    // sample offset of the wave's first read (wave-uniform)
+    int32_t maxn;  // longest read of the wave (wave-uniform)
+    __device__ __forceinline__ void load(const EvArgs &a, int lane, int64_t *lds_b, int32_t *lds_n, bool *live, int64_t *b_out,
+                                         int32_t *n_out) {
+        const int i = blockIdx.x * 64 + lane;
+        *live = i < a.n_reads;
+        const int last = a.n_reads - 1;
+        *b_out = a.raw_off[*live ? i : last];
+        *n_out = *live ? static_cast<int32_t>(a.raw_off[i + 1] - *b_out) : 0;
+        lds_b[lane] = *b_out;
+        lds_n[lane] = *n_out;
+        int m = *n_out;
+        for (int o = 32; o; o >>= 1) m = max(m, __shfl_xor(m, o));
+        maxn = m;
+        __syncthreads();
+        b0 = lds_b[0];
+        const int half = lane >> 5;
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            rel[it] = static_cast<uint32_t>(lds_b[2 * it + half] - b0);
+            len[it] = lds_n[2 * it + half];
+        }
+    }
+};
+
 // event_single(): pA = ((float)raw + offset) * raw_unit; compute_sum_sumsq(): sequential double prefix sums, the
-// square being a FLOAT product that is promoted afterwards (src/events.c:297-307).  One read per lane.
+// square being a FLOAT product that is promoted afterwards (src/events.c:297-307).  One read per lane, LDS tiles.
 __global__ void __launch_bounds__(64) ev_prefix_kernel(const EvArgs a) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n_reads) return;
-    const int64_t b = a.raw_off[i], n = a.raw_off[i + 1] - b;
-    const float off = a.scale[2 * i], unit = a.scale[2 * i + 1];
-    double *s = a.sum + b + i, *q = a.sumsq + b + i;
+    __shared__ float raw_t[64][kEvTile + 1];
+    __shared__ double s_t[64][kEvTile + 1];
+    __shared__ double q_t[64][kEvTile + 1];
+    __shared__ int64_t lds_b[64];
+    __shared__ int32_t lds_n[64];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    bool live;
+    int64_t b;
+    int32_t n;
+    TileReads tr;
+    tr.load(a, lane, lds_b, lds_n, &live, &b, &n);
+    const float off = live ? a.scale[2 * i] : 0.0f, unit = live ? a.scale[2 * i + 1] : 0.0f;
+    if (live) {
+        a.sum[b + i] = 0.0;
+        a.sumsq[b + i] = 0.0;
+    }
+    const int16_t *rawp = a.raw + tr.b0;
+    double *sump = a.sum + tr.b0 + static_cast<int64_t>(blockIdx.x) * 64 + 1;  // read i owns [raw_off[i] + i, ...)
+    double *sqp = a.sumsq + tr.b0 + static_cast<int64_t>(blockIdx.x) * 64 + 1;
     double acc = 0.0, acc2 = 0.0;
-    s[0] = 0.0;
-    q[0] = 0.0;
-    for (int64_t j = 0; j < n; ++j) {
-        const float pa = (static_cast<float>(a.raw[b + j]) + off) * unit;
-        const float sq = pa * pa;
-        acc = acc + static_cast<double>(pa);
-        acc2 = acc2 + static_cast<double>(sq);
-        s[j + 1] = acc;
-        q[j + 1] = acc2;
+    const int half = lane >> 5, j = lane & 31;
+    // coalesced: 32 consecutive samples of read r per half-wave; all loads of a tile are in flight together, and the
+    // next tile is fetched while this one is summed.  A position past the end of its read is fetched from sample 0 and
+    // yields garbage sums that are never stored (a read's tail is its last tile).
+    float v[32];
+    auto fetch = [&](int base) {
+        const int bj = base + j;
+#pragma unroll
+        for (int it = 0; it < 32; ++it) v[it] = static_cast<float>(rawp[bj < tr.len[it] ? tr.rel[it] + static_cast<uint32_t>(bj) : 0u]);
+    };
+    fetch(0);
+    for (int base = 0; base < tr.maxn; base += kEvTile) {
+#pragma unroll
+        for (int it = 0; it < 32; ++it) raw_t[2 * it + half][j] = v[it];
+        if (base + kEvTile < tr.maxn) fetch(base + kEvTile);
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < kEvTile; ++jj) {
+            const float pa = (raw_t[lane][jj] + off) * unit;
+            const float sq = pa * pa;
+            acc = acc + static_cast<double>(pa);
+            acc2 = acc2 + static_cast<double>(sq);
+            s_t[lane][jj] = acc;
+            q_t[lane][jj] = acc2;
+        }
+        __syncthreads();
+        const int bj = base + j;
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            if (bj < tr.len[it]) {
+                const uint32_t o = tr.rel[it] + static_cast<uint32_t>(bj + 2 * it + half);
+                sump[o] = s_t[2 * it + half][j];
+                sqp[o] = q_t[2 * it + half][j];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -89,85 +166,139 @@ __global__ void __launch_bounds__(256) ev_tstat_kernel(const EvArgs a) {
     }
 }
 
-// short_long_peak_detector() + create_events(), src/events.c:375-508.  One read per lane; an event is written as soon
-// as its closing peak fires.
-struct PeakDet {
+// short_long_peak_detector() + the event boundaries of create_events(), src/events.c:375-508.  One read per lane over
+// LDS tiles of the two t-statistics; an event START is written as soon as its closing peak fires, the statistics of
+// the events follow in ev_stats_kernel.
+struct PeakDet32 {  // PeakDet with 32-bit positions (a read has < 2^31 samples)
     float threshold;
     int window;
-    int64_t masked_to;
-    int64_t peak_pos;  // -1: none
+    int masked_to;
+    int peak_pos;  // -1: none
     float peak_value;
     bool valid;
 };
 
-__device__ __forceinline__ void emit_event(const EvArgs &a, const double *s, const double *q, int64_t slot, int64_t start, int64_t end) {
-    const float length = static_cast<float>(end - start);
-    const float mean = static_cast<float>(s[end] - s[start]) / length;  // create_event(), src/events.c:461-477
-    const float dsq = static_cast<float>(q[end] - q[start]);
-    const float var = dsq / length - mean * mean;
-    a.ev_start[slot] = static_cast<int32_t>(start);
-    a.ev_length[slot] = length;
-    a.ev_mean[slot] = mean;
-    a.ev_stdv[slot] = sqrtf(fmaxf(var, 0.0f));
-}
-
 __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n_reads) return;
-    const int64_t b = a.raw_off[i], n = a.raw_off[i + 1] - b;
-    const double *s = a.sum + b + i, *q = a.sumsq + b + i;
-    const float *sig[2] = {a.t1 + b, a.t2 + b};
-    const int64_t eo = a.ev_off[i], ecap = a.ev_off[i + 1] - eo;
-    PeakDet d[2];
-    d[0] = PeakDet{a.thr1, a.w1, 0, -1, 3.402823466e+38f, false};
-    d[1] = PeakDet{a.thr2, a.w2, 0, -1, 3.402823466e+38f, false};
-    int64_t nev = 0, last = 0;  // events written, start of the open event
-    for (int64_t j = 0; j < n; ++j) {
+    __shared__ float t_t[2][64][kEvTile + 1];
+    __shared__ int64_t lds_b[64];
+    __shared__ int32_t lds_n[64];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * 64 + lane;
+    bool live;
+    int64_t b;
+    int32_t n;
+    TileReads tr;
+    tr.load(a, lane, lds_b, lds_n, &live, &b, &n);
+    const int64_t eo = live ? a.ev_off[i] : 0;
+    const int ecap = live ? static_cast<int>(a.ev_off[i + 1] - eo) : 0;
+    int32_t *evs = a.ev_start + eo;
+    const float *t1p = a.t1 + tr.b0, *t2p = a.t2 + tr.b0;
+    PeakDet32 d[2];
+    d[0] = PeakDet32{a.thr1, a.w1, 0, -1, 3.402823466e+38f, false};
+    d[1] = PeakDet32{a.thr2, a.w2, 0, -1, 3.402823466e+38f, false};
+    int nev = 0, last = 0;  // events opened so far, start of the open event
+    const int half = lane >> 5, jl = lane & 31;
+    // all loads of a tile in flight together; the next tile is fetched while the detectors walk this one
+    float v0[32], v1[32];
+    auto fetch = [&](int base) {
+        const int bj = base + jl;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            PeakDet &p = d[k];
-            if (p.masked_to >= j) continue;
-            const float cur = sig[k][j];
-            if (p.peak_pos == -1) {
-                if (cur < p.peak_value) {
-                    p.peak_value = cur;
-                } else if (cur - p.peak_value > a.peak_height) {
-                    p.peak_value = cur;
-                    p.peak_pos = j;
-                }
-            } else {
-                if (cur > p.peak_value) {
-                    p.peak_value = cur;
-                    p.peak_pos = j;
-                }
-                if (k == 0 && p.peak_value > p.threshold) {  // the short detector masks the long one
-                    d[1].masked_to = p.peak_pos + p.window;
-                    d[1].peak_pos = -1;
-                    d[1].peak_value = 3.402823466e+38f;
-                    d[1].valid = false;
-                }
-                if (p.peak_value - cur > a.peak_height && p.peak_value > p.threshold) p.valid = true;
-                if (p.valid && (j - p.peak_pos) > p.window / 2) {
-                    const int64_t pk = p.peak_pos;
-                    if (pk > 0 && pk < n && nev < ecap) {  // create_events() skips peaks at 0 / >= n
-                        emit_event(a, s, q, eo + nev, last, pk);
-                        ++nev;
-                        last = pk;
+        for (int it = 0; it < 32; ++it) {
+            const uint32_t o = bj < tr.len[it] ? tr.rel[it] + static_cast<uint32_t>(bj) : 0u;
+            v0[it] = t1p[o];
+            v1[it] = t2p[o];
+        }
+    };
+    fetch(0);
+    for (int base = 0; base < tr.maxn; base += kEvTile) {
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            t_t[0][2 * it + half][jl] = v0[it];
+            t_t[1][2 * it + half][jl] = v1[it];
+        }
+        if (base + kEvTile < tr.maxn) fetch(base + kEvTile);
+        __syncthreads();
+        const int cnt = min(kEvTile, n - base);
+        float c0[kEvTile], c1[kEvTile];  // this lane's row of the tile
+#pragma unroll
+        for (int jj = 0; jj < kEvTile; ++jj) {
+            c0[jj] = t_t[0][lane][jj];
+            c1[jj] = t_t[1][lane][jj];
+        }
+        // (a select-only formulation of the state machine was measured 25 % slower than these branches)
+#pragma unroll
+        for (int jj = 0; jj < kEvTile; ++jj) {
+            if (jj >= cnt) continue;
+            const int j = base + jj;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                PeakDet32 &p = d[k];
+                if (p.masked_to >= j) continue;
+                const float cur = k ? c1[jj] : c0[jj];
+                if (p.peak_pos == -1) {
+                    if (cur < p.peak_value) {
+                        p.peak_value = cur;
+                    } else if (cur - p.peak_value > a.peak_height) {
+                        p.peak_value = cur;
+                        p.peak_pos = j;
                     }
-                    p.peak_pos = -1;
-                    p.peak_value = cur;
-                    p.valid = false;
+                } else {
+                    if (cur > p.peak_value) {
+                        p.peak_value = cur;
+                        p.peak_pos = j;
+                    }
+                    if (k == 0 && p.peak_value > p.threshold) {  // the short detector masks the long one
+                        d[1].masked_to = p.peak_pos + p.window;
+                        d[1].peak_pos = -1;
+                        d[1].peak_value = 3.402823466e+38f;
+                        d[1].valid = false;
+                    }
+                    if (p.peak_value - cur > a.peak_height && p.peak_value > p.threshold) p.valid = true;
+                    if (p.valid && (j - p.peak_pos) > p.window / 2) {
+                        const int pk = p.peak_pos;
+                        if (pk > 0 && pk < n && nev < ecap) {  // create_events() skips peaks at 0 / >= n
+                            evs[nev] = last;
+                            ++nev;
+                            last = pk;
+                        }
+                        p.peak_pos = -1;
+                        p.peak_value = cur;
+                        p.valid = false;
+                    }
                 }
             }
         }
+        __syncthreads();
     }
+    if (!live) return;
     if (nev > 0 && nev < ecap) {  // the last event runs to the end of the signal; no peak at all -> no events
-        emit_event(a, s, q, eo + nev, last, n);
+        evs[nev] = last;
         ++nev;
     } else if (nev >= ecap) {
         nev = 0;
     }
-    a.n_events[i] = static_cast<int32_t>(nev);
+    a.n_events[i] = nev;
+}
+
+// create_event(), src/events.c:461-477: event e of a read spans [start_e, start_{e+1}) (the last one ends with the
+// signal).  One block per read, one event per thread.
+__global__ void __launch_bounds__(256) ev_stats_kernel(const EvArgs a) {
+    const int i = blockIdx.x;
+    const int64_t b = a.raw_off[i], n = a.raw_off[i + 1] - b;
+    const double *s = a.sum + b + i, *q = a.sumsq + b + i;
+    const int64_t eo = a.ev_off[i];
+    const int nev = a.n_events[i];
+    for (int e = threadIdx.x; e < nev; e += 256) {
+        const int64_t start = a.ev_start[eo + e];
+        const int64_t end = (e + 1 < nev) ? static_cast<int64_t>(a.ev_start[eo + e + 1]) : n;
+        const float length = static_cast<float>(end - start);
+        const float mean = static_cast<float>(s[end] - s[start]) / length;
+        const float dsq = static_cast<float>(q[end] - q[start]);
+        const float var = dsq / length - mean * mean;
+        a.ev_length[eo + e] = length;
+        a.ev_mean[eo + e] = mean;
+        a.ev_stdv[eo + e] = sqrtf(fmaxf(var, 0.0f));
+    }
 }
 
 // normalise_single(), src/sigfish.c:483-502 + the query extraction of dtw_single (857-867, reversal is done by the

@@ -6,7 +6,7 @@
 namespace sfa {
 #define SFA_FILL_DECL(MR, TR, SD) extern template __global__ void sdtw_fill_kernel<MR, TR, SD>(const DpArgs);
 #define SFA_TRACE_DECL(MR, SD) extern template __global__ void sdtw_trace_kernel<MR, SD>(const DpArgs, int32_t *);
-#define SFA_FOR_MAXR(X, ...) X(4, __VA_ARGS__) X(8, __VA_ARGS__) X(16, __VA_ARGS__) X(32, __VA_ARGS__) X(128, __VA_ARGS__)
+#define SFA_FOR_MAXR(X, ...) X(4, __VA_ARGS__) X(8, __VA_ARGS__) X(16, __VA_ARGS__) X(32, __VA_ARGS__)
 SFA_FOR_MAXR(SFA_FILL_DECL, false, false)
 SFA_FOR_MAXR(SFA_FILL_DECL, false, true)
 SFA_FOR_MAXR(SFA_FILL_DECL, true, false)

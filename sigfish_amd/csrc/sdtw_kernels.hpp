@@ -14,7 +14,10 @@
 //     a wave.  Lane g of a row owns R consecutive query rows (R = 4/8/16/32 -> queries up to 64/128/256/512
 //     events), kept in VGPRs together with their running cost.  No barriers, no cost matrix.  Queries longer
 //     than 512 events take 32 or 64 lanes per read at R = 32 (two reads / one read per wave, up to 1024 / 2048
-//     events); everything below is written for L lanes per read.
+//     events); everything below is written for L lanes per read.  SMALL BATCHES use the same freedom the other
+//     way round: when there are too few reads to fill the chip the planner halves or quarters R and doubles or
+//     quadruples L (q = 250: 8 rows x 32 lanes or 4 rows x 64 lanes), which gives 2-4x the waves, each with
+//     a 2-4x shorter step -- latency per batch drops accordingly.
 //   * the lanes of a row walk an anti-diagonal: at step t lane g is at reference column t-g, so the only
 //     cross-lane traffic per step is ONE value per lane, the bottom cost handed to the next lane (through a
 //     wave-private LDS window, see Exchange): the neighbour's value from the previous step is this lane's "up",
@@ -47,7 +50,7 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #define SFA_FILL_WAVES 6  // waves per SIMD the cost-only fill (R <= 16) is register-budgeted for: 80 VGPRs
 #endif
 constexpr int kStepsPerLoad = SFA_STEPS_PER_LOAD;  // reference levels fetched per load (4 = one 16-byte load)
-constexpr int kMaxClasses = 6;     // query-length classes (R, lanes) = (32,64) (32,32) (32,16) (16,16) (8,16) (4,16)
+constexpr int kMaxClasses = 6;     // query-length classes; base shapes (R, lanes) = (32,64) (32,32) (32,16) (16,16) (8,16) (4,16)
 
 struct __attribute__((packed, aligned(4))) float4u {
     float v[kStepsPerLoad];
@@ -373,17 +376,18 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     }
 }
 
-// Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill.
-template <int R, bool TRACK, bool STD, int I = 0>
+// Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill in the
+// throughput shapes (16 lanes per read).
+template <int R, bool TRACK, bool STD, bool STATIC_RQ, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
                                                const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T) {
-    if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
+    if constexpr (TRACK || STD || R > 16 || !STATIC_RQ) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
         sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
     } else {
         if (rq == I) {
             sweep_job<R, TRACK, STD, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+            sweep_dispatch<R, TRACK, STD, STATIC_RQ, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
         }
     }
 }
@@ -421,7 +425,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+        sweep_dispatch<R, TRACK, STD, L == 16>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
     }
 
     if (g == lq && read >= 0) {
@@ -434,9 +438,8 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     }
 }
 
-// grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR (query rows per 16 lanes: 4..32,
-// 64 = two DPP rows per read, 128 = a whole wave per read) bounds the classes compiled in, so a batch without
-// long queries does not pay the long variant's register budget.
+// grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR (rows per lane) bounds the shapes
+// compiled in, so a batch without long queries does not pay the long variant's register budget.
 template <int MAXR, bool TRACK, bool STD>
 __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES : 1) sdtw_fill_kernel(const DpArgs a) {
     const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -448,26 +451,20 @@ __global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES :
     const int tl = task - cd.task_base;
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
-    switch (cd.R * (cd.lanes >> 4)) {  // query rows per 16 lanes
-        case 128:
-            if constexpr (MAXR >= 128) fill_body<32, 64, TRACK, STD>(a, cd, tl, lds_f, lds_i);
-            break;
-        case 64:
-            if constexpr (MAXR >= 64) fill_body<32, 32, TRACK, STD>(a, cd, tl, lds_f, lds_i);
-            break;
-        case 32:
-            if constexpr (MAXR >= 32) fill_body<32, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
-            break;
-        case 16:
-            if constexpr (MAXR >= 16) fill_body<16, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
-            break;
-        case 8:
-            if constexpr (MAXR >= 8) fill_body<8, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
-            break;
+#define SFA_SHAPE(RR, LL)                                                                   \
+    case (RR) * 256 + (LL):                                                                 \
+        if constexpr (MAXR >= (RR)) fill_body<RR, LL, TRACK, STD>(a, cd, tl, lds_f, lds_i); \
+        break;
+    switch (cd.R * 256 + cd.lanes) {
+        SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
+        SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
+        SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
+        SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
         default:
             fill_body<4, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
     }
+#undef SFA_SHAPE
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -635,26 +632,20 @@ __global__ void __launch_bounds__(256) sdtw_trace_kernel(const DpArgs a, int32_t
     const int tl = task - cd.task_base;
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[4 * kXchWordsPerWave];
-    switch (cd.R * (cd.lanes >> 4)) {
-        case 128:
-            if constexpr (MAXR >= 128) trace_body<32, 64, STD>(a, cd, tl, out_st, lds_f, lds_i);
-            break;
-        case 64:
-            if constexpr (MAXR >= 64) trace_body<32, 32, STD>(a, cd, tl, out_st, lds_f, lds_i);
-            break;
-        case 32:
-            if constexpr (MAXR >= 32) trace_body<32, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
-            break;
-        case 16:
-            if constexpr (MAXR >= 16) trace_body<16, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
-            break;
-        case 8:
-            if constexpr (MAXR >= 8) trace_body<8, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
-            break;
+#define SFA_SHAPE(RR, LL)                                                                    \
+    case (RR) * 256 + (LL):                                                                  \
+        if constexpr (MAXR >= (RR)) trace_body<RR, LL, STD>(a, cd, tl, out_st, lds_f, lds_i); \
+        break;
+    switch (cd.R * 256 + cd.lanes) {
+        SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
+        SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
+        SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
+        SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
         default:
             trace_body<4, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
             break;
     }
+#undef SFA_SHAPE
 }
 
 // src/sigfish.c:979-983: (int)round(500*(score2-score)/score) with x86 cvttsd2si saturation, cap 60, store u8

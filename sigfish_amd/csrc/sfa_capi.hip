@@ -114,6 +114,8 @@ struct sfa_ctx {
     int64_t opt_single_pass = 0;             // 1: one fill with start tracking everywhere (first-round design)
     int64_t opt_ckpt_interval = 0;           // force the checkpoint interval (power of two >= 4); 0 = auto
     int64_t opt_ckpt_budget = 32ll << 30;    // bytes of HBM the checkpoints of one batch may take
+    int64_t opt_lane_widening = 0;           // 0 = by batch size; 1, 2, 4 = fixed (rows per lane / w, lanes per read * w)
+    int64_t opt_widen_below = 2;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
 
@@ -152,9 +154,7 @@ void launch_fill(int maxr, bool std_dtw, const DpArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, true>), grid, block, 0, st, a);           \
     else                                                                                               \
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, false>), grid, block, 0, st, a)
-    if (maxr > 32) {
-        SFA_FILL(128);
-    } else if (maxr >= 32) {
+    if (maxr >= 32) {
         SFA_FILL(32);
     } else if (maxr >= 16) {
         SFA_FILL(16);
@@ -173,9 +173,7 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
         hipLaunchKernelGGL((sfa::sdtw_trace_kernel<MR, true>), grid, block, 0, st, a, out_st);         \
     else                                                                                               \
         hipLaunchKernelGGL((sfa::sdtw_trace_kernel<MR, false>), grid, block, 0, st, a, out_st)
-    if (maxr > 32) {
-        SFA_TRACE(128);
-    } else if (maxr >= 32) {
+    if (maxr >= 32) {
         SFA_TRACE(32);
     } else if (maxr >= 16) {
         SFA_TRACE(16);
@@ -198,6 +196,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.ckpt_interval = c->opt_ckpt_interval;
     pp.ckpt_budget_bytes = c->opt_ckpt_budget;
     pp.trace_margin = c->opt_trace_margin;
+    pp.lane_widening = c->opt_lane_widening;
+    pp.widen_below = c->opt_widen_below;
     sfa::BatchPlan plan;
     std::string perr;
     if (int rc = sfa::plan_batch(q_off, n, c->h_job_len, c->total_cols, pp, &plan, &perr)) return fail(rc, "%s", perr.c_str());
@@ -292,9 +292,9 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (n_quads > 0) {
         if (plan.single_pass)
-            launch_fill<true>(plan.max_span / 16, std_dtw, da, st);
+            launch_fill<true>(plan.max_R, std_dtw, da, st);
         else
-            launch_fill<false>(plan.max_span / 16, std_dtw, da, st);
+            launch_fill<false>(plan.max_R, std_dtw, da, st);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));
@@ -306,7 +306,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         DpArgs ta = da;
         for (int i = 0; i < ta.n_cls; ++i) ta.cls[i].task_base = ta.cls[i].quad_base;  // one task per quad
         ta.n_tasks = n_quads;
-        launch_trace(plan.max_span / 16, std_dtw, ta, c->d_tst.as<int32_t>(), st);
+        launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[3], st));
         fz.mode = 2;
@@ -460,6 +460,12 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
         c->opt_ckpt_budget = value;
     } else if (k == "trace_margin") {
         c->opt_trace_margin = value;
+    } else if (k == "lane_widening") {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SFA_EINVAL, "lane_widening must be 0 (auto), 1, 2 or 4");
+        c->opt_lane_widening = value;
+    } else if (k == "widen_below") {
+        if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
+        c->opt_widen_below = value;
     } else if (k == "waves_per_simd") {
         if (value < 1 || value > 8) return fail(SFA_EINVAL, "waves_per_simd must be 1..8");
         c->opt_waves_per_simd = value;
@@ -621,6 +627,7 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     hipLaunchKernelGGL(sfa::ev_prefix_kernel, lane_grid, lane_block, 0, st, ea);
     hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, st, ea);
     hipLaunchKernelGGL(sfa::ev_peaks_kernel, lane_grid, lane_block, 0, st, ea);
+    hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, st, ea);
     HIP_TRY(hipGetLastError());
     std::vector<int32_t> nev(n);
     HIP_TRY(hipMemcpyAsync(nev.data(), c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));

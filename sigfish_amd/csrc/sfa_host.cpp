@@ -108,7 +108,7 @@ int32_t sfa_gen_ref_record(const char *seq, int32_t len, const float *level_mean
 }
 
 int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len, int32_t n_jobs, int64_t ckpt_interval,
-                   int64_t ckpt_budget_bytes, int32_t *slot_of_read, sfa_plan_info_t *info) {
+                   int64_t ckpt_budget_bytes, int32_t lane_widening, int32_t *slot_of_read, sfa_plan_info_t *info) {
     if (!q_off || n_reads < 0 || !job_len || n_jobs <= 0 || !info) return SFA_EINVAL;
     std::vector<int32_t> jl(job_len, job_len + n_jobs);
     int64_t total = 0;
@@ -116,6 +116,8 @@ int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len
     sfa::PlanParams pp;
     pp.ckpt_interval = ckpt_interval;
     if (ckpt_budget_bytes > 0) pp.ckpt_budget_bytes = ckpt_budget_bytes;
+    if (lane_widening != 0 && lane_widening != 1 && lane_widening != 2 && lane_widening != 4) return SFA_EINVAL;
+    pp.lane_widening = lane_widening;
     sfa::BatchPlan plan;
     std::string err;
     if (int rc = sfa::plan_batch(q_off, n_reads, jl, total, pp, &plan, &err)) return rc;
@@ -129,7 +131,7 @@ int sfa_plan_batch(const int64_t *q_off, int32_t n_reads, const int32_t *job_len
     info->ckpt_bytes = plan.ck_floats * 4;
     info->n_tasks = static_cast<int64_t>(plan.n_quads) * plan.n_chunks;
     info->max_lanes_per_read = plan.max_lanes;
-    info->reserved = 0;
+    info->lane_widening = plan.widening;
     return SFA_OK;
 }
 

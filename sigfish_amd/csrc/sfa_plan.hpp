@@ -5,6 +5,8 @@
 //   * reads of EQUAL query length are grouped four at a time into "quads" (one wavefront each); lengths select
 //     a rows-per-lane class R (4/8/16/32) -- long classes first so that short work fills the tail; queries of
 //     513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read per "quad";
+//   * SMALL BATCHES: when the waves of a batch would not fill the chip, every class trades rows per lane for lanes
+//     per read (R/2 x 2L or R/4 x 4L, "lane widening" 2 or 4): 2-4x the waves, each with a 2-4x shorter step;
 //   * the (contig,strand) job list is cut into contiguous chunks of similar size when there are too few quads
 //     to fill the chip; a wave-task is (quad, chunk);
 //   * the checkpoint interval T of pass 1 is the smallest power of two >= 512 whose checkpoints fit the budget.
@@ -25,6 +27,17 @@ struct ClassShape {
 // classes in task order (long first)
 constexpr ClassShape kClassShapes[6] = {{32, 64}, {32, 32}, {32, 16}, {16, 16}, {8, 16}, {4, 16}};
 
+// shape of base class ci under lane widening w (1, 2, 4): rows per lane halve while lanes per read double
+inline ClassShape widened(int ci, int w) {
+    ClassShape s = kClassShapes[ci];
+    while (w > 1 && s.lanes < 64 && s.R > 4) {
+        s.R /= 2;
+        s.lanes *= 2;
+        w /= 2;
+    }
+    return s;
+}
+
 inline int class_for(int qlen) {  // index into kClassShapes, -1: too long
     if (qlen > kMaxQuery) return -1;
     int c = 0;
@@ -43,6 +56,8 @@ struct PlanParams {
     int64_t ckpt_interval = 0;      // 0 = auto
     int64_t ckpt_budget_bytes = 32ll << 30;
     int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
+    int64_t lane_widening = 0;      // 0 = auto (by batch size), else 1, 2 or 4
+    int64_t widen_below = 2;        // auto: widen (x4) when the batch has fewer than this many waves per SIMD
 };
 
 struct PlanClass {
@@ -51,7 +66,7 @@ struct PlanClass {
 };
 
 struct BatchPlan {
-    int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, max_span = 64, ck_shift = 0, trace_margin = 0;
+    int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, widening = 1, ck_shift = 0, trace_margin = 0;
     bool single_pass = false;
     int64_t ck_floats = 0, query_events = 0;
     std::vector<int32_t> order;         // [4*max(n_quads,1)] read per (quad,slot) or -1
@@ -101,27 +116,56 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     }
     std::vector<int32_t> count(maxq + 2, 0);
     for (int32_t i = 0; i < n; ++i) count[qlen[i]]++;
-    // classes in task order (long first); inside a class by descending length
+    // classes in task order (long first); inside a class by descending length.  layout(w) fills the plan for lane
+    // widening w and returns the number of quads (waves' worth of reads).
     std::vector<int32_t> quad_start(maxq + 2, -1);
-    int32_t n_quads = 0;
-    for (int ci = 0; ci < 6; ++ci) {
-        PlanClass cl;
-        cl.R = kClassShapes[ci].R;
-        cl.lanes = kClassShapes[ci].lanes;
-        cl.quad_base = n_quads;
-        const int per = 64 / cl.lanes;  // reads per wave
-        for (int l = maxq; l >= 1; --l) {
-            if (count[l] == 0 || class_for(l) != ci) continue;
-            quad_start[l] = n_quads;
-            n_quads += (count[l] + per - 1) / per;
+    auto layout = [&](int w) {
+        p.classes.clear();
+        int32_t n_quads = 0;
+        for (int ci = 0; ci < 6; ++ci) {
+            const ClassShape sh = widened(ci, w);
+            PlanClass cl;
+            cl.R = sh.R;
+            cl.lanes = sh.lanes;
+            cl.quad_base = n_quads;
+            const int per = 64 / cl.lanes;  // reads per wave
+            for (int l = maxq; l >= 1; --l) {
+                if (count[l] == 0 || class_for(l) != ci) continue;
+                quad_start[l] = n_quads;
+                n_quads += (count[l] + per - 1) / per;
+            }
+            cl.n_quads = n_quads - cl.quad_base;
+            if (cl.n_quads > 0) p.classes.push_back(cl);
         }
-        cl.n_quads = n_quads - cl.quad_base;
-        if (cl.n_quads > 0) p.classes.push_back(cl);
+        return n_quads;
+    };
+    auto chunks_for = [&](int32_t n_quads) -> int32_t {  // chunk the job list only as far as needed to fill the machine
+        if (n_quads <= 0 || n_jobs <= 1) return 1;
+        // equal-length tasks finish in rounds; ask for >= 16 rounds so the last, partly filled one costs ~3 %
+        const int64_t target = pp.n_sims * pp.waves_per_simd * 16;
+        return static_cast<int32_t>(std::min<int64_t>(n_jobs, std::max<int64_t>(1, (target + n_quads - 1) / n_quads)));
+    };
+    int w = 1;
+    int32_t n_quads = layout(1);
+    if (pp.lane_widening > 0) {
+        w = static_cast<int>(pp.lane_widening);
+        if (w != 1) n_quads = layout(w);
+    } else {
+        // measured (tools/small_batches.sh, nCoV, q = 250): below ~2 waves per SIMD a batch is latency-bound and the
+        // 4-rows-per-lane shapes halve its time; above, the 16-lane shapes are 25-40 % more efficient; x2 never wins
+        if (static_cast<int64_t>(n_quads) * chunks_for(n_quads) < pp.widen_below * pp.n_sims) {
+            w = 4;
+            n_quads = layout(w);
+        }
     }
+    p.widening = w;
     p.n_quads = n_quads;
-    p.max_R = p.classes.empty() ? 4 : p.classes.front().R;
-    p.max_lanes = p.classes.empty() ? 16 : p.classes.front().lanes;
-    p.max_span = p.max_R * p.max_lanes;
+    p.max_R = 4;
+    p.max_lanes = 16;
+    for (const PlanClass &cl : p.classes) {
+        p.max_R = std::max(p.max_R, cl.R);
+        p.max_lanes = std::max(p.max_lanes, cl.lanes);
+    }
     p.order.assign(4 * static_cast<size_t>(std::max(n_quads, 1)), -1);
     p.quad_qlen.assign(std::max(n_quads, 1), 1);
     p.slot_of_read.assign(n, -1);
@@ -130,24 +174,19 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         const int l = qlen[i];
         if (l == 0) continue;
         const int32_t k = fill_pos[l]++;
-        const int per = 64 / kClassShapes[class_for(l)].lanes;
-        const int32_t sl = (quad_start[l] + k / per) * 4 + (k % per);  // a wave always has four slots; long classes use 2 / 1
+        const int per = 64 / widened(class_for(l), w).lanes;
+        const int32_t sl = (quad_start[l] + k / per) * 4 + (k % per);  // a wave always has four slots; wide shapes use 2 / 1
         p.order[sl] = i;
         p.slot_of_read[i] = sl;
     }
     for (int l = 1; l <= maxq; ++l)
         if (count[l]) {
-            const int per = 64 / kClassShapes[class_for(l)].lanes;
+            const int per = 64 / widened(class_for(l), w).lanes;
             for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + per - 1) / per; ++qd) p.quad_qlen[qd] = l;
         }
 
     // chunk the job list only as far as needed to fill the machine
-    p.n_chunks = 1;
-    if (n_quads > 0 && n_jobs > 1) {
-        // equal-length tasks finish in rounds; ask for >= 16 rounds so the last, partly filled one costs ~3 %
-        const int64_t target = pp.n_sims * pp.waves_per_simd * 16;
-        p.n_chunks = static_cast<int32_t>(std::min<int64_t>(n_jobs, std::max<int64_t>(1, (target + n_quads - 1) / n_quads)));
-    }
+    p.n_chunks = chunks_for(n_quads);
     p.chunk_begin.resize(p.n_chunks + 1);
     split_jobs(job_len, total_cols, p.n_chunks, p.chunk_begin.data());
 

@@ -94,7 +94,7 @@ def test_plan_batch_layout():
     rng = np.random.default_rng(3)
     lens = rng.choice([0, 1, 25, 64, 65, 128, 129, 250, 250, 250, 256, 257, 512], size=1000)
     q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    info, slot = plan_batch(q_off, [29898, 29898])
+    info, slot = plan_batch(q_off, [29898, 29898], lane_widening=1)
     assert (slot[lens == 0] == -1).all()
     used = slot[lens > 0]
     assert len(np.unique(used)) == len(used)            # one slot per read
@@ -111,10 +111,10 @@ def test_plan_batch_layout():
     rpl = np.select([l_sorted <= 64, l_sorted <= 128, l_sorted <= 256], [4, 8, 16], 32)
     assert (np.diff(rpl) <= 0).all()
     # a tight budget raises the interval instead of failing
-    info2, _ = plan_batch(q_off, [29898, 29898], ckpt_budget_bytes=1 << 20)
+    info2, _ = plan_batch(q_off, [29898, 29898], ckpt_budget_bytes=1 << 20, lane_widening=1)
     assert info2["ckpt_interval"] > 512 and info2["ckpt_bytes"] <= 1 << 20
     # few reads, many contigs: the contig list is chunked to fill the machine
-    info3, _ = plan_batch(np.array([0, 250, 500], np.int64), [375] * 160)
+    info3, _ = plan_batch(np.array([0, 250, 500], np.int64), [375] * 160, lane_widening=1)
     assert info3["n_quads"] == 1 and info3["n_chunks"] == 160
     assert info["max_lanes_per_read"] == 16
     with pytest.raises(S.SfaError):
@@ -126,7 +126,7 @@ def test_plan_batch_long_queries():
     from sigfish_amd.api import plan_batch
     lens = np.array([2048, 1025, 1025, 1024, 1024, 1024, 513, 512, 512, 250, 250, 250, 250, 250, 600, 600])
     q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    info, slot = plan_batch(q_off, [5000])
+    info, slot = plan_batch(q_off, [5000], lane_widening=1)
     assert info["max_lanes_per_read"] == 64 and info["max_rows_per_lane"] == 32 and info["n_classes"] == 4
     assert info["trace_margin"] == 2048 + 64
     quad, sl = slot >> 2, slot & 3
@@ -142,8 +142,36 @@ def test_plan_batch_long_queries():
     span = np.select([lens[order] <= 64, lens[order] <= 128, lens[order] <= 256, lens[order] <= 512, lens[order] <= 1024],
                      [64, 128, 256, 512, 1024], 2048)
     assert (np.diff(span) <= 0).all()
-    info2, _ = plan_batch(np.array([0, 700], np.int64), [100])
+    info2, _ = plan_batch(np.array([0, 700], np.int64), [100], lane_widening=1)
     assert info2["max_lanes_per_read"] == 32 and info2["trace_margin"] == 700 + 32
+
+
+def test_plan_batch_lane_widening():
+    """Small batches trade rows per lane for lanes per read: 2-4x the waves, each with a 2-4x shorter step."""
+    from sigfish_amd.api import plan_batch
+    lens = np.array([250] * 10 + [100] * 3 + [500, 60, 1000, 2000])
+    q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    i1, s1 = plan_batch(q_off, [29898, 29898], lane_widening=1)
+    i2, s2 = plan_batch(q_off, [29898, 29898], lane_widening=2)
+    i4, s4 = plan_batch(q_off, [29898, 29898], lane_widening=4)
+    # w=1: 2000 -> 1 wave, 1000 -> 1, 500 -> 1, 250x10 -> 3, 100x3 -> 1, 60 -> 1
+    assert (i1["n_quads"], i1["lane_widening"], i1["max_lanes_per_read"]) == (8, 1, 64)
+    # w=2: 250 -> (8 rows, 32 lanes): 5 waves; 100 -> (4,32): 2 waves; 500 -> (16,32); 60 stays (4,16); 1000 -> (16,64)
+    assert (i2["n_quads"], i2["lane_widening"]) == (1 + 1 + 1 + 5 + 2 + 1, 2)
+    # w=4: 250 -> (4,64): 10 waves; 100 -> (4,32) (rows per lane cannot drop below 4): 2; 500 -> (8,64)
+    assert (i4["n_quads"], i4["lane_widening"]) == (1 + 1 + 1 + 10 + 2 + 1, 4)
+    for s, per250 in ((s1, 4), (s2, 2), (s4, 1)):
+        assert len(np.unique(s)) == len(s)
+        assert ((s[:10] & 3) < per250).all()
+    # auto: a small batch widens fully, a big one does not (1024 SIMDs assumed, fewer than 2 waves per SIMD widens)
+    assert plan_batch(q_off, [29898, 29898])[0]["lane_widening"] == 4
+    big = np.arange(0, 250 * 20001, 250, dtype=np.int64)
+    assert plan_batch(big, [29898, 29898])[0]["lane_widening"] == 1
+    mid = np.arange(0, 250 * 4097, 250, dtype=np.int64)      # 1024 waves x 2 chunks = 2 per SIMD: stays
+    assert plan_batch(mid, [29898, 29898])[0]["lane_widening"] == 1
+    assert plan_batch(mid[:2049], [29898, 29898])[0]["lane_widening"] == 4
+    with pytest.raises(S.SfaError):
+        plan_batch(q_off, [100], lane_widening=3)
 
 
 def test_plan_batch_empty_and_single():

@@ -27,8 +27,13 @@ def assert_rows_equal(got, want):
     assert np.array_equal(got["score2"][v].view(np.uint32), want["score2"][v].view(np.uint32))
 
 
-# the two-pass default, the single-pass variant, and a configuration that forces dense checkpoints + back-off
-MODES = {"two_pass": {}, "single_pass": {"single_pass": 1}, "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0}}
+# the two-pass default, the single-pass variant, a configuration that forces dense checkpoints + back-off (all three
+# pinned to the throughput shapes, 16 lanes per read), the small-batch shapes (rows per lane / 2 and / 4), and what the
+# planner picks by itself for these small batches
+MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "lane_widening": 1},
+         "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
+         "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
+         "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}
 
 
 def _aligner(ref, flag, mode="two_pass"):

@@ -11,7 +11,7 @@ with open("/tmp/syn6.model", "w") as f:
     for kmer, v in zip(itertools.product("ACGT", repeat=6), lv):
         f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
 PY
-for K in 4096 16384; do
+for K in ${KS:-4096 16384}; do
   T0=$(date +%s.%N)
   sigfish_amd/bin/sigfish-amd dtw --kmer-model /tmp/syn6.model -t $THREADS -K $K -B 2G --verbose 3 \
       tests/golden/data/nCoV-2019.reference.fasta /tmp/big.blow5 > /tmp/big.paf
