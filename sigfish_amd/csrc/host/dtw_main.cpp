@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <future>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -235,17 +236,20 @@ int dtw_main(int argc, char **argv) {
         rp[i] = rna ? nullptr : rev[i].data();
     }
     sfa_ref_t sref{nref, ref_len.data(), ref_off.data(), fp.data(), rna ? nullptr : rp.data()};
-    sfa_ctx_t *ctx = nullptr;
-    if (sfa_init(&ctx, &sref, o.flag, o.device) != SFA_OK) die(std::string("accelerator init failed: ") + sfa_last_error());
+    // two contexts (streams + scratch) on the same device: consecutive batches alternate between them, so the uploads
+    // and the event detection of batch i+1 overlap the DTW of batch i
+    sfa_ctx_t *ctxs[2] = {nullptr, nullptr};
+    for (sfa_ctx_t *&c : ctxs)
+        if (sfa_init(&c, &sref, o.flag, o.device) != SFA_OK) die(std::string("accelerator init failed: ") + sfa_last_error());
 
     if (o.flag & F_SAM) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
         for (int32_t i = 0; i < nref; ++i) fprintf(stdout, "@SQ\tSN:%s\tLN:%ld\n", contigs[i].name.c_str(), static_cast<long>(ref_len[i]));
         fprintf(stdout, "@PG\tID:sigfish\tPN:sigfish\tVN:0.2.0\n");
     }
 
-    // ---- batch loop, src/dtw_main.c:299-326, as a two-slot pipeline: while the GPU stage and the output of batch i
-    // run on a helper thread, the main thread loads and pre-processes batch i+1.  Batches are aligned and printed
-    // strictly in order, so the output is the same as the serial loop's. ----
+    // ---- batch loop, src/dtw_main.c:299-326, as a pipeline over four slots: while the GPU stages of batches i and i-1
+    // (one per context) and the output of batch i-2 run on helper threads, the main thread loads and pre-processes
+    // batch i+1.  Batches are printed strictly in order, so the output is the same as the serial loop's. ----
     double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
     int64_t total = 0, prefix_fail = 0, ignored = 0, too_short = 0, sum_bytes = 0;
     struct Slot {
@@ -264,7 +268,7 @@ int dtw_main(int argc, char **argv) {
     };
     // events on the GPU unless SAM (needs the event tables on the host) or the RNA auto prefix (adaptor/poly-A on host)
     const bool gpu_events = !o.host_events && !(o.flag & F_SAM) && o.prefix >= 0;
-    Slot slots[2];
+    Slot slots[4];
     for (Slot &sl : slots) {
         sl.reads.resize(o.batch_size);
         sl.evp.resize(o.batch_size);
@@ -273,11 +277,11 @@ int dtw_main(int argc, char **argv) {
         sl.qe.resize(o.batch_size);
         sl.rows.resize(o.batch_size);
     }
-    auto align_and_output = [&](Slot &sl) {
+    std::mutex stat_mu;  // two GPU stages may finish together
+    auto align = [&](Slot &sl, sfa_ctx_t *ctx) {
         const int32_t n = sl.n;
-        std::vector<Read> &batch = sl.reads;
         std::vector<sfa_result_t> &rows = sl.rows;
-        double a = realtime();
+        const double a = realtime();
         if (gpu_events) {
             sl.info.resize(n);
             if (n > 0 && sfa_align_raw(ctx, sl.raw, sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
@@ -286,6 +290,7 @@ int dtw_main(int argc, char **argv) {
         } else if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK) {
             die(std::string("alignment failed: ") + sfa_last_error());
         }
+        std::lock_guard<std::mutex> lock(stat_mu);
         t_dtw += realtime() - a;
         if (gpu_events)
             for (int32_t i = 0; i < n; ++i) {
@@ -294,7 +299,12 @@ int dtw_main(int argc, char **argv) {
             }
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) processed\n", realtime() - t0, cputime() / (realtime() - t0), n, sl.bytes / 1e6);
-        a = realtime();
+    };
+    auto output = [&](Slot &sl) {
+        const int32_t n = sl.n;
+        std::vector<Read> &batch = sl.reads;
+        std::vector<sfa_result_t> &rows = sl.rows;
+        const double a = realtime();
         if (o.flag & F_SAM) {
             // the warp path of every winner is rebuilt on the host from its band (sam.hpp), one read per task
             std::vector<std::string> sam(n);
@@ -341,12 +351,12 @@ int dtw_main(int argc, char **argv) {
         t_out += realtime() - a;
     };
 
-    std::future<void> pending;
-    int cur = 0;
+    std::future<void> gpu_pending[2], out_pending;  // GPU stage of the even / odd batches, output
+    int64_t bi = 0;                                 // batch index; batch bi lives in slot bi % 4 and on context bi % 2
     int32_t counter = 0;
     bool more = true;
     while (more) {
-        Slot &sl = slots[cur];
+        Slot &sl = slots[bi % 4];
         std::vector<Read> &batch = sl.reads;
         double a = realtime();
         int32_t n = 0;
@@ -426,17 +436,30 @@ int dtw_main(int argc, char **argv) {
             too_short += (r.status & 1) != 0;
         }
         t_proc += realtime() - a;
-        if (pending.valid()) pending.get();  // batch i-1 is out before batch i enters the GPU stage
-        pending = std::async(std::launch::async, [&align_and_output, &slots, cur] { align_and_output(slots[cur]); });
-        cur ^= 1;
+        if (gpu_pending[bi & 1].valid()) gpu_pending[bi & 1].get();  // batch bi-2 has its rows, its context is free
+        if (out_pending.valid()) out_pending.get();                // batch bi-3 is printed (its slot is filled next)
+        if (bi >= 2) {
+            Slot *done = &slots[(bi - 2) % 4];
+            out_pending = std::async(std::launch::async, [&output, done] { output(*done); });
+        }
+        {
+            Slot *mine = &sl;
+            sfa_ctx_t *c = ctxs[bi & 1];
+            gpu_pending[bi & 1] = std::async(std::launch::async, [&align, mine, c] { align(*mine, c); });
+        }
+        ++bi;
         total += n;
         sum_bytes += bytes;
         if (o.debug_break == counter) break;
         ++counter;
     }
-    if (pending.valid()) pending.get();
+    if (out_pending.valid()) out_pending.get();
+    for (int64_t b = std::max<int64_t>(bi - 2, 0); b < bi; ++b) {  // the last two batches, in order
+        if (gpu_pending[b & 1].valid()) gpu_pending[b & 1].get();
+        output(slots[b % 4]);
+    }
     for (Slot &sl : slots) sfa_pinned_free(sl.raw);
-    sfa_destroy(ctx);
+    for (sfa_ctx_t *c : ctxs) sfa_destroy(c);
     if (o.verbosity >= 3) {
         fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld\n", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);
         fprintf(stderr, "[dtw_main] total bytes: %.1f M\n[dtw_main] Data loading time: %.3f sec\n", sum_bytes / 1e6, t_load);
