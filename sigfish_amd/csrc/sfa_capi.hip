@@ -114,6 +114,7 @@ struct sfa_ctx {
     int64_t opt_single_pass = 0;             // 1: one fill with start tracking everywhere (first-round design)
     int64_t opt_ckpt_interval = 0;           // force the checkpoint interval (power of two >= 4); 0 = auto
     int64_t opt_ckpt_budget = 32ll << 30;    // bytes of HBM the checkpoints of one batch may take
+    int64_t opt_min_slice_reads = 65536;     // a batch is only cut into slices of at least this many reads
     int64_t opt_lane_widening = 0;           // 0 = by batch size; 1, 2, 4 = fixed (rows per lane / w, lanes per read * w)
     int64_t opt_widen_below = 2;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
@@ -135,6 +136,7 @@ struct sfa_ctx {
 
     sfa_profile_t prof{};
     bool prof_pending = false;
+    bool in_slice = false;   // align_device is running one slice of a cut-up batch
     int32_t pending_n = -1;  // reads of the batch submitted with sfa_submit_batch and not yet collected
 };
 
@@ -185,6 +187,38 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
 #undef SFA_TRACE
 }
 
+int resolve_profile(sfa_ctx *c);
+int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out);
+
+// A batch so large that its checkpoints only fit the budget at a long interval (a long pass 2) is cut into slices
+// of contiguous reads that keep the interval short; slices of >= 64 Ki reads still fill the chip.  Slices run one
+// after the other (each is planned and staged on its own), so such a call is synchronous.
+
+int align_sliced(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out, int32_t slices) {
+    sfa_profile_t sum{};
+    for (int32_t s = 0; s < slices; ++s) {
+        const int32_t lo = static_cast<int32_t>(static_cast<int64_t>(n) * s / slices);
+        const int32_t hi = static_cast<int32_t>(static_cast<int64_t>(n) * (s + 1) / slices);
+        c->in_slice = true;
+        int rc = align_device(c, d_queries, q_off + lo, hi - lo, d_out + lo);  // q_off holds absolute offsets into d_queries
+        c->in_slice = false;
+        if (rc) return rc;
+        if ((rc = resolve_profile(c))) return rc;  // waits for the slice: the staging area is reused by the next one
+        sum.fill_ms += c->prof.fill_ms;
+        sum.trace_ms += c->prof.trace_ms;
+        sum.finalize_ms += c->prof.finalize_ms;
+        sum.total_ms += c->prof.total_ms;
+        sum.cells += c->prof.cells;
+        sum.fill_launches += c->prof.fill_launches;
+        sum.ckpt_interval = std::max(sum.ckpt_interval, c->prof.ckpt_interval);
+        sum.ckpt_bytes = std::max(sum.ckpt_bytes, c->prof.ckpt_bytes);
+        sum.n_tasks += c->prof.n_tasks;
+        sum.n_chunks = std::max(sum.n_chunks, c->prof.n_chunks);
+    }
+    c->prof = sum;
+    return SFA_OK;
+}
+
 // Core of both align entry points: queries already in HBM, results left in HBM.
 int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out) {
     if (n == 0) return SFA_OK;
@@ -201,6 +235,12 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     sfa::BatchPlan plan;
     std::string perr;
     if (int rc = sfa::plan_batch(q_off, n, c->h_job_len, c->total_cols, pp, &plan, &perr)) return fail(rc, "%s", perr.c_str());
+    if (!c->in_slice && !plan.single_pass && c->opt_ckpt_interval == 0 && plan.ck_shift > 9 && n >= 2 * c->opt_min_slice_reads) {
+        // checkpoints at T = 512 would take about ck_bytes * T/512
+        const int64_t want = (plan.ck_floats * 4 * (1ll << (plan.ck_shift - 9)) + pp.ckpt_budget_bytes - 1) / std::max<int64_t>(pp.ckpt_budget_bytes, 1);
+        const int32_t slices = static_cast<int32_t>(std::min<int64_t>(want, n / c->opt_min_slice_reads));
+        if (slices > 1) return align_sliced(c, d_queries, q_off, n, d_out, slices);
+    }
 
     const int32_t n_quads = plan.n_quads, n_chunks = plan.n_chunks, n_jobs = c->n_jobs;
     // staging layout: q_off[n+1] | order[4*n_quads] | quad_qlen[n_quads] | slot[n] | chunk_begin[n_chunks+1] | job_ck_off[n_jobs+1]
@@ -463,6 +503,9 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "lane_widening") {
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SFA_EINVAL, "lane_widening must be 0 (auto), 1, 2 or 4");
         c->opt_lane_widening = value;
+    } else if (k == "min_slice_reads") {
+        if (value < 1) return fail(SFA_EINVAL, "min_slice_reads must be >= 1");
+        c->opt_min_slice_reads = value;
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
         c->opt_widen_below = value;

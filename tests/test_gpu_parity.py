@@ -185,6 +185,22 @@ def test_checkpoint_budget_picks_larger_interval():
     assert a.tobytes() == b.tobytes()
 
 
+def test_huge_batch_is_sliced(oracle):
+    """A batch whose checkpoints exceed the budget at T = 512 is cut into slices of contiguous reads; rows unchanged."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=300, seed=31)
+    with S.Aligner(ref, flag) as al:
+        whole = al.align_db(q, q_off)
+        p0 = al.profile()
+        al.set_option("ckpt_budget_bytes", 8 << 20)   # 300 reads need ~40 MB at T = 512
+        al.set_option("min_slice_reads", 40)
+        sliced = al.align_db(q, q_off)
+        p1 = al.profile()
+    assert sliced.tobytes() == whole.tobytes()
+    assert p1["fill_launches"] > 1 and p0["fill_launches"] == 1 and p1["cells"] == p0["cells"]
+    assert p1["ckpt_interval"] == 512 and p1["ckpt_bytes"] <= 8 << 20
+    assert_rows_equal(whole, oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16))
+
+
 def test_long_reference_1mb(oracle):
     """BASELINE config 4 shape (1 Mb reference, k=9): the oracle needs a 1 GB matrix per read and strand, so three
     reads; the GPU uses a larger checkpoint interval only if the budget says so (here it does not)."""
