@@ -51,10 +51,13 @@ def test_cli_host_events_path(name, models):
     assert r.stdout.decode() == c["out_text"]
 
 
-def test_cli_small_batches_keep_order(models):
-    """-K 2 forces several batches; output order and content must not change."""
-    c = load_case("rna_default")
-    cmd = [BIN, "dtw", "--kmer-model", models[5], "--verbose", "0", "-K", "3", "--rna", c["fasta"], c["blow5"]]
+@pytest.mark.parametrize("k", [1, 2, 3])
+@pytest.mark.parametrize("extra", [[], ["--host-events"], ["--sam"]])
+def test_cli_small_batches_keep_order(models, k, extra):
+    """-K 1..3 forces up to eight batches through the four-slot / two-context pipeline; output order and content
+    must not change (8 reads: batches overlap on the device and in the output thread)."""
+    c = load_case("rna_sam" if "--sam" in extra else "rna_default")
+    cmd = [BIN, "dtw", "--kmer-model", models[5], "--verbose", "0", "-K", str(k), "--rna", *extra, c["fasta"], c["blow5"]]
     r = subprocess.run(cmd, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout.decode() == c["out_text"]
