@@ -49,6 +49,9 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #ifndef SFA_FILL_WAVES
 #define SFA_FILL_WAVES 6  // waves per SIMD the cost-only fill (R <= 16) is register-budgeted for: 80 VGPRs
 #endif
+#ifndef SFA_FILL32_WAVES
+#define SFA_FILL32_WAVES 4  // the R = 32 shapes: 128 VGPRs (a handful of spills outside the loop); 81.5 -> 79.6 ms at q = 500
+#endif
 constexpr int kStepsPerLoad = SFA_STEPS_PER_LOAD;  // reference levels fetched per load (4 = one 16-byte load)
 constexpr int kMaxClasses = 6;     // query-length classes; base shapes (R, lanes) = (32,64) (32,32) (32,16) (16,16) (8,16) (4,16)
 
@@ -341,13 +344,13 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         };
         // two blocks per iteration so that the prefetched levels alternate between two register sets (no copies)
         int b = 0;
-        for (; b + 1 < nb; b += 2) {
+        for (; R < 32 && b + 1 < nb; b += 2) {  // (at R = 32 the paired body costs 66 more VGPRs than the 4 copies it saves)
             const float4u yb = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
             block(ycur);
             ycur = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
             block(yb);
         }
-        if (b < nb) {
+        for (; b < nb; ++b) {
             const float4u yb = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
             block(ycur);
             ycur = yb;
@@ -441,7 +444,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
 // grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR (rows per lane) bounds the shapes
 // compiled in, so a batch without long queries does not pay the long variant's register budget.
 template <int MAXR, bool TRACK, bool STD>
-__global__ void __launch_bounds__(256, (MAXR <= 16 && !TRACK) ? SFA_FILL_WAVES : 1) sdtw_fill_kernel(const DpArgs a) {
+__global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES))) sdtw_fill_kernel(const DpArgs a) {
     const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
     if (task >= a.n_tasks) return;  // wave-uniform
