@@ -4,6 +4,7 @@
 
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <immintrin.h>
 #include <zlib.h>
 
 #include <cstring>
@@ -44,7 +45,60 @@ bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> *dst) {
     return true;
 }
 
-// StreamVByte (scalar form) + zig-zag delta -> int16 samples
+// StreamVByte + zig-zag delta -> int16 samples.  Key byte k holds the byte counts (minus one) of four values; the
+// SSSE3 path expands them with one pshufb per key byte (shuffle table built once), un-zigzags and prefix-sums four
+// deltas at a time; the scalar loop handles the tail and machines without SSSE3.
+struct SvbTables {
+    uint8_t shuf[256][16];
+    uint8_t len[256];
+    SvbTables() {
+        for (int k = 0; k < 256; ++k) {
+            int pos = 0;
+            for (int v = 0; v < 4; ++v) {
+                const int nb = ((k >> (2 * v)) & 3) + 1;
+                for (int b = 0; b < 4; ++b) shuf[k][4 * v + b] = b < nb ? static_cast<uint8_t>(pos + b) : 0x80;  // 0x80 -> zero byte
+                pos += nb;
+            }
+            len[k] = static_cast<uint8_t>(pos);
+        }
+    }
+};
+const SvbTables &svb_tables() {
+    static const SvbTables t;
+    return t;
+}
+
+__attribute__((target("ssse3"))) size_t decode_svb_zd_ssse3(const uint8_t *keys, const uint8_t **datap, const uint8_t *end, uint32_t n,
+                                                            int16_t *out, int32_t *prevp) {
+    const SvbTables &t = svb_tables();
+    const uint8_t *data = *datap;
+    __m128i prev = _mm_set1_epi32(*prevp);
+    size_t i = 0;
+    // 16 readable bytes are needed per group; the last groups go through the scalar loop
+    for (; i + 4 <= n && static_cast<size_t>(end - data) >= 16; i += 4) {
+        const unsigned k = keys[i >> 2];
+        const __m128i raw = _mm_loadu_si128(reinterpret_cast<const __m128i *>(data));
+        const __m128i v = _mm_shuffle_epi8(raw, _mm_loadu_si128(reinterpret_cast<const __m128i *>(t.shuf[k])));
+        data += t.len[k];
+        // zig-zag: (v >> 1) ^ -(v & 1)
+        const __m128i d = _mm_xor_si128(_mm_srli_epi32(v, 1), _mm_sub_epi32(_mm_setzero_si128(), _mm_and_si128(v, _mm_set1_epi32(1))));
+        // inclusive prefix sum of the four deltas on top of the running value
+        __m128i s = _mm_add_epi32(d, _mm_slli_si128(d, 4));
+        s = _mm_add_epi32(s, _mm_slli_si128(s, 8));
+        s = _mm_add_epi32(s, prev);
+        prev = _mm_shuffle_epi32(s, 0xff);
+        alignas(16) int32_t tmp[4];
+        _mm_store_si128(reinterpret_cast<__m128i *>(tmp), s);
+        out[i] = static_cast<int16_t>(tmp[0]);
+        out[i + 1] = static_cast<int16_t>(tmp[1]);
+        out[i + 2] = static_cast<int16_t>(tmp[2]);
+        out[i + 3] = static_cast<int16_t>(tmp[3]);
+    }
+    *prevp = _mm_cvtsi128_si32(prev);
+    *datap = data;
+    return i;
+}
+
 bool decode_svb_zd(const uint8_t *p, size_t nbytes, std::vector<int16_t> *out) {
     if (nbytes < 4) return false;
     uint32_t n;
@@ -56,7 +110,10 @@ bool decode_svb_zd(const uint8_t *p, size_t nbytes, std::vector<int16_t> *out) {
     const uint8_t *end = p + nbytes;
     out->resize(n);
     int32_t prev = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+    size_t i = 0;
+    static const bool have_ssse3 = __builtin_cpu_supports("ssse3");
+    if (have_ssse3) i = decode_svb_zd_ssse3(keys, &data, end, n, out->data(), &prev);
+    for (; i < n; ++i) {
         const unsigned code = (keys[i >> 2] >> ((i & 3) * 2)) & 3u;  // bytes-1 of value i
         if (static_cast<size_t>(end - data) < code + 1) return false;
         uint32_t v = 0;

@@ -1,8 +1,8 @@
 #!/bin/bash
-# End-to-end throughput of the command line on a replicated fixture (run on the GPU box):  tools/e2e_cli.sh [copies] [threads]
+# End-to-end throughput of the command line on a replicated fixture (run on the GPU box):  [BLOW5_FLAGS=--compress] [KS="4096 16384"] tools/e2e_cli.sh [copies] [threads]
 set -e
 COPIES=${1:-4000}; THREADS=${2:-16}
-python tools/make_blow5.py tests/golden/data/sp1_dna.blow5 /tmp/big.blow5 --copies $COPIES
+python tools/make_blow5.py tests/golden/data/sp1_dna.blow5 /tmp/big.blow5 --copies $COPIES $BLOW5_FLAGS
 python - <<'PY'
 import itertools, numpy as np
 lv = np.fromfile("tests/golden/models/syn6.f32", np.float32)

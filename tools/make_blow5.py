@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""make_blow5.py -- write a large UNCOMPRESSED BLOW5 file by replicating the reads of a fixture (SURVEY.md §8d
-"end-to-end synthetic inputs"), to measure the `sigfish-amd dtw` command line end to end.
+"""make_blow5.py -- write a large BLOW5 file by replicating the reads of a fixture (SURVEY.md §8d "end-to-end synthetic
+inputs"), to measure the `sigfish-amd dtw` command line end to end.  Uncompressed by default; --compress writes what
+real files use: StreamVByte zig-zag-delta signals inside zlib records.
 
     python tools/make_blow5.py tests/golden/data/sp1_dna.blow5 /tmp/big.blow5 --copies 4000
 
@@ -12,9 +13,27 @@ import argparse
 import os
 import struct
 import sys
+import zlib
+
+import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sigfish_amd as S  # noqa: E402
+
+
+def svb_zd(raw):
+    """int16 samples -> u32 n | StreamVByte keys (2 bits per value: bytes-1) | little-endian data bytes of the zig-zag deltas."""
+    x = raw.astype(np.int32)
+    d = np.diff(x, prepend=np.int32(0))
+    z = ((d << 1) ^ (d >> 31)).astype(np.uint32)
+    nb = np.where(z < (1 << 8), 1, np.where(z < (1 << 16), 2, np.where(z < (1 << 24), 3, 4))).astype(np.uint8)
+    n = len(z)
+    codes = np.zeros((n + 3) // 4 * 4, np.uint8)
+    codes[:n] = nb - 1
+    keys = (codes[0::4] | (codes[1::4] << 2) | (codes[2::4] << 4) | (codes[3::4] << 6)).astype(np.uint8)
+    b = z.view(np.uint8).reshape(n, 4)  # little-endian bytes of every value
+    mask = np.arange(4)[None, :] < nb[:, None]
+    return struct.pack("<I", n) + keys.tobytes() + b[mask].tobytes()
 
 
 def main():
@@ -22,6 +41,7 @@ def main():
     ap.add_argument("src")
     ap.add_argument("dst")
     ap.add_argument("--copies", type=int, default=1000)
+    ap.add_argument("--compress", action="store_true", help="zlib records + svb-zd signals (as real BLOW5 files)")
     a = ap.parse_args()
     f = S.Blow5File(a.src)
     reads = list(f)
@@ -29,16 +49,20 @@ def main():
     text = "".join(f"@{k}\t{v}\n" for k, v in attrs)
     text += "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
     text += "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
-    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([0]) + struct.pack("<I", 1) + bytes([0])
+    press = 1 if a.compress else 0
+    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([press]) + struct.pack("<I", 1) + bytes([press])
     hdr += b"\0" * (64 - len(hdr)) + struct.pack("<I", len(text)) + text.encode()
     n = 0
     with open(a.dst, "wb") as out:
         out.write(hdr)
+        sig = [svb_zd(raw) if a.compress else raw.tobytes() for _, _, raw in reads]
         for c in range(a.copies):
-            for rid, meta, raw in reads:
+            for (rid, meta, raw), body in zip(reads, sig):
                 name = f"{rid}_{c}".encode()
                 payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, meta["digitisation"], meta["offset"], meta["range"],
-                                                                          meta["sampling_rate"], len(raw)) + raw.tobytes()
+                                                                          meta["sampling_rate"], len(body) if a.compress else len(raw)) + body
+                if a.compress:
+                    payload = zlib.compress(payload, 6)
                 out.write(struct.pack("<Q", len(payload)) + payload)
                 n += 1
         out.write(b"5WOLB")
