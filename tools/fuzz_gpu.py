@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """fuzz_gpu.py -- randomised parity campaign of the HIP path against the oracle (run on an MI355X box):
 random reference shapes, ragged query lengths, DNA / RNA / std-DTW / invert, quantised values (exact ties),
-random checkpoint intervals and trace margins.  Usage: python tools/fuzz_gpu.py [iterations] [seed]"""
+random checkpoint intervals, trace margins and lane shapes.  Usage: python tools/fuzz_gpu.py [iterations] [seed]"""
 import os
 import sys
 import time
@@ -48,6 +48,7 @@ def main():
             opts["trace_margin"] = int(rng.choice([0, 3, 50, 300]))
         if rng.integers(0, 5) == 0:
             opts["single_pass"] = 1
+        opts["lane_widening"] = int(rng.choice([0, 1, 1, 2, 4]))  # small batches widen by themselves; pin the other shapes too
         with S.Aligner(ref, flag) as al:
             for k, v in opts.items():
                 al.set_option(k, v)
