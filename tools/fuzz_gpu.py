@@ -63,6 +63,8 @@ def main():
             print(f"MISMATCH it={it} mode={mode} quant={quant} lens={lens} n={n} opts={opts} reads={idx}")
             for i in idx:
                 print("   qlen", qlens[i], "got", got[i], "want", want[i])
+        if (it + 1) % 1000 == 0:  # a silent GPU job is taken to be hung
+            print(f"  {it + 1} iterations, {bad} mismatching batches so far, {time.time() - t0:.0f} s", flush=True)
     print(f"{iters} iterations, {bad} mismatching batches, {time.time() - t0:.1f} s")
     sys.exit(1 if bad else 0)
 
