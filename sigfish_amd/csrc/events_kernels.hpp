@@ -33,6 +33,8 @@ struct EvArgs {
     int32_t *n_events;      // [n]
     int32_t n_reads;
     int32_t w1, w2;         // detector windows (3,6 DNA / 7,14 RNA)
+    int32_t *seq_flag;      // [n] written by ev_prefix_par_kernel: 1 = this read needs the sequential prefix sums
+    int32_t use_flags;      // 0: ev_prefix_kernel sums every read; 1: only the flagged ones
     float thr1, thr2, peak_height;
 };
 
@@ -47,11 +49,11 @@ struct TileReads {
     int64_t b0;    // sample offset of the wave's first read (wave-uniform)
     int32_t maxn;  // longest read of the wave (wave-uniform)
     __device__ __forceinline__ void load(const EvArgs &a, int lane, int64_t *lds_b, int32_t *lds_n, bool *live, int64_t *b_out,
-                                         int32_t *n_out) {
+                                         int32_t *n_out, bool flagged_only = false) {
         const int i = blockIdx.x * 64 + lane;
-        *live = i < a.n_reads;
+        *live = i < a.n_reads && !(flagged_only && a.seq_flag[i] == 0);
         const int last = a.n_reads - 1;
-        *b_out = a.raw_off[*live ? i : last];
+        *b_out = a.raw_off[i < a.n_reads ? i : last];
         *n_out = *live ? static_cast<int32_t>(a.raw_off[i + 1] - *b_out) : 0;
         lds_b[lane] = *b_out;
         lds_n[lane] = *n_out;
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(64) ev_prefix_kernel(const EvArgs a) {
     int64_t b;
     int32_t n;
     TileReads tr;
-    tr.load(a, lane, lds_b, lds_n, &live, &b, &n);
+    tr.load(a, lane, lds_b, lds_n, &live, &b, &n, a.use_flags != 0);
     const float off = live ? a.scale[2 * i] : 0.0f, unit = live ? a.scale[2 * i + 1] : 0.0f;
     if (live) {
         a.sum[b + i] = 0.0;
@@ -129,6 +131,76 @@ __global__ void __launch_bounds__(64) ev_prefix_kernel(const EvArgs a) {
             }
         }
         __syncthreads();
+    }
+}
+
+// The same prefix sums with the 64 lanes of a wave on ONE read -- allowed whenever the additions cannot round.  All
+// addends are integer multiples of the ulp q of the smallest one; if the sum of their magnitudes stays below 2^52 q,
+// every partial sum, in ANY order, is an integer multiple of q below 2^53 q, i.e. exactly representable: no addition
+// rounds, the parallel scan and the reference's sequential loop both return the true sums, bit for bit.  Real signal
+// passes (pA values span a few binades, 10^4..10^6 samples); a read that does not is flagged and left to
+// ev_prefix_kernel.  One wave per read: pass 1 = the certificate, pass 2 = the scan, 64 samples per step.
+__device__ __forceinline__ double wave_inclusive_scan(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double u = __shfl_up(v, o);
+        v = lane >= o ? v + u : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64) ev_prefix_par_kernel(const EvArgs a) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int64_t b = a.raw_off[i];
+    const int32_t n = static_cast<int32_t>(a.raw_off[i + 1] - b);
+    const float off = a.scale[2 * i], unit = a.scale[2 * i + 1];
+    const int16_t *raw = a.raw + b;
+    // ---- pass 1: smallest exponent among the non-zero addends, sum of magnitudes ----
+    int e_pa = 255, e_sq = 255;  // biased exponents; 255 = "none seen"
+    bool finite = true;
+    double m_pa = 0.0, m_sq = 0.0;
+    for (int32_t j = lane; j < n; j += 64) {
+        const float pa = (static_cast<float>(raw[j]) + off) * unit;
+        const float sq = pa * pa;
+        const int xp = static_cast<int>((__float_as_uint(pa) >> 23) & 0xffu), xs = static_cast<int>((__float_as_uint(sq) >> 23) & 0xffu);
+        finite = finite && xp != 255 && xs != 255;
+        if (pa != 0.0f) e_pa = min(e_pa, max(xp, 1));  // denormals: exponent field 0, ulp 2^-149 like field 1
+        if (sq != 0.0f) e_sq = min(e_sq, max(xs, 1));
+        m_pa += fabs(static_cast<double>(pa));
+        m_sq += static_cast<double>(sq);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        e_pa = min(e_pa, __shfl_xor(e_pa, o));
+        e_sq = min(e_sq, __shfl_xor(e_sq, o));
+        m_pa += __shfl_xor(m_pa, o);
+        m_sq += __shfl_xor(m_sq, o);
+    }
+    finite = __all(finite);
+    // ulp of a float with biased exponent e is 2^(e-150); bound 2^52 ulp (one bit of slack covers the rounding of m_*)
+    const bool exact = finite && m_pa < ldexp(1.0, e_pa - 98) && m_sq < ldexp(1.0, e_sq - 98);
+    if (lane == 0) a.seq_flag[i] = exact ? 0 : 1;
+    if (!exact) return;
+    // ---- pass 2: scan ----
+    double *s = a.sum + b + i, *q = a.sumsq + b + i;
+    if (lane == 0) {
+        s[0] = 0.0;
+        q[0] = 0.0;
+    }
+    double carry = 0.0, carry2 = 0.0;
+    for (int32_t base = 0; base < n; base += 64) {
+        const int32_t j = base + lane;
+        float pa = 0.0f;
+        if (j < n) pa = (static_cast<float>(raw[j]) + off) * unit;
+        const float sq = pa * pa;
+        const double v = wave_inclusive_scan(static_cast<double>(pa), lane) + carry;
+        const double v2 = wave_inclusive_scan(static_cast<double>(sq), lane) + carry2;
+        if (j < n) {
+            s[j + 1] = v;
+            q[j + 1] = v2;
+        }
+        carry = __shfl(v, 63);
+        carry2 = __shfl(v2, 63);
     }
 }
 

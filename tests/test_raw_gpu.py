@@ -84,3 +84,33 @@ def test_raw_path_many_reads_equals_host_path():
     m = want["valid"] == 1
     assert rows[m].tobytes() == want[m].tobytes()
     assert np.array_equal(info["qstart"][m], np.array(qs)[m]) and np.array_equal(info["qend"][m], np.array(qe)[m])
+
+
+def test_parallel_prefix_sums_and_their_fallback():
+    """The wave-per-read prefix sums run only where no addition can round; reads that fail the certificate (here: a tiny
+    offset turns raw == 0 into 1e-30 pA next to ordinary values, > 52 bits apart) go through the sequential kernel.
+    Both routes and the all-sequential setting give the same events, windows and rows as the host stages."""
+    c = load_case("dna_default")
+    ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
+    ids, raw, off, scal = _load_raw(c["blow5"])
+    raws, scs = [], []
+    for k in range(130):  # more than two waves of reads, alternating certified / uncertified
+        i = k % 5
+        r = raw[off[i]:off[i + 1]].copy()
+        sc = np.array(scal[i], np.float64)
+        if k % 2 == 1:
+            sc[1] = 1e-30     # offset: (float)0 + 1e-30 is a tiny non-zero pA value
+            r[::97] = 0
+        raws.append(r)
+        scs.append(sc)
+    off2 = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int64)
+    raw2 = np.concatenate(raws)
+    with S.Aligner(ref, 0) as al:
+        rows_par, info_par = al.align_raw(raw2, off2, np.array(scs), 50, 250)
+        al.set_option("ev_parallel_prefix", 0)
+        rows_seq, info_seq = al.align_raw(raw2, off2, np.array(scs), 50, 250)
+    assert rows_par.tobytes() == rows_seq.tobytes() and info_par.tobytes() == info_seq.tobytes()
+    for k in (0, 1, 2, 3, 64, 65, 129):  # host stages on a few of each kind
+        meta = dict(digitisation=scs[k][0], offset=scs[k][1], range=scs[k][2])
+        ev = S.detect_events(raws[k], meta, False)
+        assert info_par["n_events"][k] == len(ev)
