@@ -9,6 +9,8 @@
 #include <sys/time.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <future>
 #include <mutex>
 #include <cmath>
@@ -103,25 +105,79 @@ struct Read {
     int status = 0;
 };
 
-template <typename F>
-void parallel_for(int64_t n, int nthreads, F fn) {  // work_db(): one fan-out per stage, atomic work queue
-    if (nthreads <= 1 || n <= 1) {
-        for (int64_t i = 0; i < n; ++i) fn(i);
-        return;
+// work_db() of the reference forks and joins `-t` threads for every stage of every batch (src/thread.c:119-132); here
+// the workers are created once and woken per stage.  Items are handed out through an atomic counter,
+// the calling thread works too.  Several threads may call run() (the loader and the output stage do): calls queue up.
+class WorkerPool {
+  public:
+    explicit WorkerPool(int nthreads) {
+        for (int t = 1; t < nthreads; ++t) workers_.emplace_back([this] { loop(); });
     }
-    std::atomic<int64_t> next(0);
-    std::vector<std::thread> pool;
-    const int nt = static_cast<int>(std::min<int64_t>(nthreads, n));
-    for (int t = 0; t < nt; ++t)
-        pool.emplace_back([&] {
-            for (;;) {
-                const int64_t i = next.fetch_add(1);
-                if (i >= n) break;
-                fn(i);
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    template <typename F>
+    void run(int64_t n, F fn) {
+        if (workers_.empty() || n <= 1) {
+            for (int64_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> one_job(submit_mu_);
+        std::function<void(int64_t)> f = fn;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &f;
+            n_ = n;
+            next_.store(0);
+            busy_ = static_cast<int>(workers_.size());
+            ++generation_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    void drain() {
+        for (;;) {
+            const int64_t i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
             }
-        });
-    for (auto &th : pool) th.join();
-}
+            drain();
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--busy_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, submit_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::atomic<int64_t> next_{0};
+    const std::function<void(int64_t)> *fn_ = nullptr;
+    int64_t n_ = 0;
+    int busy_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace
 
@@ -251,6 +307,7 @@ int dtw_main(int argc, char **argv) {
     // (one per context) and the output of batch i-2 run on helper threads, the main thread loads and pre-processes
     // batch i+1.  Batches are printed strictly in order, so the output is the same as the serial loop's. ----
     double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
+    WorkerPool pool(o.threads);  // -t host threads, alive for the whole run
     int64_t total = 0, prefix_fail = 0, ignored = 0, too_short = 0, sum_bytes = 0;
     struct Slot {
         std::vector<Read> reads;
@@ -308,7 +365,7 @@ int dtw_main(int argc, char **argv) {
         if (o.flag & F_SAM) {
             // the warp path of every winner is rebuilt on the host from its band (sam.hpp), one read per task
             std::vector<std::string> sam(n);
-            parallel_for(n, o.threads, [&](int64_t i) {
+            pool.run(n, [&](int64_t i) {
                 const Read &r = batch[i];
                 const sfa_result_t &row = rows[i];
                 if (!r.keep || !row.valid || row.rid < 0) return;
@@ -383,7 +440,7 @@ int dtw_main(int argc, char **argv) {
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
         a = realtime();
         std::atomic<int> bad(0);
-        parallel_for(n, o.threads, [&](int64_t i) {
+        pool.run(n, [&](int64_t i) {
             Read &r = batch[i];
             std::string perr;
             if (!(r.view ? reader.parse(r.view, r.view_size, &r.rec, &perr) : reader.parse(r.mem, &r.rec, &perr))) {
@@ -421,7 +478,7 @@ int dtw_main(int argc, char **argv) {
                 sl.raw = static_cast<int16_t *>(sfa_pinned_alloc(sl.raw_cap * sizeof(int16_t)));
                 if (!sl.raw) die(std::string("cannot allocate the sample staging buffer: ") + sfa_last_error());
             }
-            parallel_for(n, o.threads, [&](int64_t i) {
+            pool.run(n, [&](int64_t i) {
                 memcpy(sl.raw + sl.raw_off[i], batch[i].rec.raw.data(), sizeof(int16_t) * batch[i].rec.raw.size());
             });
         }
