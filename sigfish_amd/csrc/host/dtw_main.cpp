@@ -41,6 +41,7 @@ struct Opt {
     int verbosity = 4;
     int device = 0;
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
+    int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     const char *model_file = nullptr;
     const char *pore = nullptr;
     int pore_flag = 0;  // 0 r9, 1 r10, 2 rna004
@@ -82,7 +83,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT               GPU to use [0]\n   --host-events              detect events on host threads instead of the GPU\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT               GPU to use [0]\n   --host-events              detect events on host threads instead of the GPU\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -194,7 +195,7 @@ int dtw_main(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -228,6 +229,7 @@ int dtw_main(int argc, char **argv) {
                 break;
             case 11: o.device = atoi(optarg); break;
             case 14: o.host_events = true; break;
+            case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }
     }
@@ -294,7 +296,9 @@ int dtw_main(int argc, char **argv) {
     sfa_ref_t sref{nref, ref_len.data(), ref_off.data(), fp.data(), rna ? nullptr : rp.data()};
     // two contexts (streams + scratch) on the same device: consecutive batches alternate between them, so the uploads
     // and the event detection of batch i+1 overlap the DTW of batch i
-    sfa_ctx_t *ctxs[2] = {nullptr, nullptr};
+    // (--streams: more than two were measured to add nothing, the stages of one batch already serialise on syncs)
+    const int n_ctx = o.streams > 0 ? o.streams : 2;
+    std::vector<sfa_ctx_t *> ctxs(n_ctx, nullptr);
     for (sfa_ctx_t *&c : ctxs)
         if (sfa_init(&c, &sref, o.flag, o.device) != SFA_OK) die(std::string("accelerator init failed: ") + sfa_last_error());
 
@@ -325,7 +329,8 @@ int dtw_main(int argc, char **argv) {
     };
     // events on the GPU unless SAM (needs the event tables on the host) or the RNA auto prefix (adaptor/poly-A on host)
     const bool gpu_events = !o.host_events && !(o.flag & F_SAM) && o.prefix >= 0;
-    Slot slots[4];
+    const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
+    std::vector<Slot> slots(n_slots);
     for (Slot &sl : slots) {
         sl.reads.resize(o.batch_size);
         sl.evp.resize(o.batch_size);
@@ -408,12 +413,13 @@ int dtw_main(int argc, char **argv) {
         t_out += realtime() - a;
     };
 
-    std::future<void> gpu_pending[2], out_pending;  // GPU stage of the even / odd batches, output
-    int64_t bi = 0;                                 // batch index; batch bi lives in slot bi % 4 and on context bi % 2
+    std::vector<std::future<void>> gpu_pending(n_ctx);  // GPU stage per context
+    std::future<void> out_pending;                      // output stage
+    int64_t bi = 0;  // batch index; batch bi lives in slot bi % n_slots and runs on context bi % n_ctx
     int32_t counter = 0;
     bool more = true;
     while (more) {
-        Slot &sl = slots[bi % 4];
+        Slot &sl = slots[bi % n_slots];
         std::vector<Read> &batch = sl.reads;
         double a = realtime();
         int32_t n = 0;
@@ -493,16 +499,16 @@ int dtw_main(int argc, char **argv) {
             too_short += (r.status & 1) != 0;
         }
         t_proc += realtime() - a;
-        if (gpu_pending[bi & 1].valid()) gpu_pending[bi & 1].get();  // batch bi-2 has its rows, its context is free
-        if (out_pending.valid()) out_pending.get();                // batch bi-3 is printed (its slot is filled next)
-        if (bi >= 2) {
-            Slot *done = &slots[(bi - 2) % 4];
+        if (gpu_pending[bi % n_ctx].valid()) gpu_pending[bi % n_ctx].get();  // batch bi-n_ctx has its rows, its context is free
+        if (out_pending.valid()) out_pending.get();  // batch bi-n_ctx-1 is printed (its slot is filled next)
+        if (bi >= n_ctx) {
+            Slot *done = &slots[(bi - n_ctx) % n_slots];
             out_pending = std::async(std::launch::async, [&output, done] { output(*done); });
         }
         {
             Slot *mine = &sl;
-            sfa_ctx_t *c = ctxs[bi & 1];
-            gpu_pending[bi & 1] = std::async(std::launch::async, [&align, mine, c] { align(*mine, c); });
+            sfa_ctx_t *c = ctxs[bi % n_ctx];
+            gpu_pending[bi % n_ctx] = std::async(std::launch::async, [&align, mine, c] { align(*mine, c); });
         }
         ++bi;
         total += n;
@@ -511,9 +517,9 @@ int dtw_main(int argc, char **argv) {
         ++counter;
     }
     if (out_pending.valid()) out_pending.get();
-    for (int64_t b = std::max<int64_t>(bi - 2, 0); b < bi; ++b) {  // the last two batches, in order
-        if (gpu_pending[b & 1].valid()) gpu_pending[b & 1].get();
-        output(slots[b % 4]);
+    for (int64_t b = std::max<int64_t>(bi - n_ctx, 0); b < bi; ++b) {  // the last batches, in order
+        if (gpu_pending[b % n_ctx].valid()) gpu_pending[b % n_ctx].get();
+        output(slots[b % n_slots]);
     }
     for (Slot &sl : slots) sfa_pinned_free(sl.raw);
     for (sfa_ctx_t *c : ctxs) sfa_destroy(c);
