@@ -39,7 +39,7 @@ struct Opt {
     int32_t prefix = 50, query = 250;
     int32_t debug_break = -1;
     int verbosity = 4;
-    int device = 0;
+    std::vector<int> devices{0};  // --device 0,1,...: batches go to the devices in turn
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     const char *model_file = nullptr;
@@ -83,7 +83,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT               GPU to use [0]\n   --host-events              detect events on host threads instead of the GPU\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -227,7 +227,19 @@ int dtw_main(int argc, char **argv) {
                 if (!strcmp(optarg, "r10")) { o.flag |= F_R10; o.pore_flag = 1; }
                 if (!strcmp(optarg, "rna004")) { o.flag |= F_RNA | F_R10; o.pore_flag = 2; }
                 break;
-            case 11: o.device = atoi(optarg); break;
+            case 11: {
+                o.devices.clear();
+                for (const char *p = optarg; *p;) {
+                    char *e = nullptr;
+                    const long d = strtol(p, &e, 10);
+                    if (e == p || d < 0) die("--device takes a comma separated list of GPU indices");
+                    o.devices.push_back(static_cast<int>(d));
+                    p = (*e == ',') ? e + 1 : e;
+                    if (*e && *e != ',') die("--device takes a comma separated list of GPU indices");
+                }
+                if (o.devices.empty()) die("--device takes a comma separated list of GPU indices");
+                break;
+            }
             case 14: o.host_events = true; break;
             case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
@@ -297,10 +309,13 @@ int dtw_main(int argc, char **argv) {
     // two contexts (streams + scratch) on the same device: consecutive batches alternate between them, so the uploads
     // and the event detection of batch i+1 overlap the DTW of batch i
     // (--streams: more than two were measured to add nothing, the stages of one batch already serialise on syncs)
-    const int n_ctx = o.streams > 0 ? o.streams : 2;
+    // Several devices (--device 0,1,...): reads shard by batch, every device holds its own copy of the reference
+    // arrays (uploaded by sfa_init: a single process needs no collective), rows come back in batch order.
+    const int n_ctx = (o.streams > 0 ? o.streams : 2) * static_cast<int>(o.devices.size());
     std::vector<sfa_ctx_t *> ctxs(n_ctx, nullptr);
-    for (sfa_ctx_t *&c : ctxs)
-        if (sfa_init(&c, &sref, o.flag, o.device) != SFA_OK) die(std::string("accelerator init failed: ") + sfa_last_error());
+    for (int j = 0; j < n_ctx; ++j)
+        if (sfa_init(&ctxs[j], &sref, o.flag, o.devices[j % o.devices.size()]) != SFA_OK)
+            die(std::string("accelerator init failed: ") + sfa_last_error());
 
     if (o.flag & F_SAM) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
         for (int32_t i = 0; i < nref; ++i) fprintf(stdout, "@SQ\tSN:%s\tLN:%ld\n", contigs[i].name.c_str(), static_cast<long>(ref_len[i]));

@@ -757,7 +757,7 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
 
 void *sfa_pinned_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {  // usable from every device's context
         fail(SFA_ENOMEM, "hipHostMalloc(%zu bytes) failed", bytes);
         return nullptr;
     }

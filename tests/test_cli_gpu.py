@@ -63,6 +63,18 @@ def test_cli_small_batches_keep_order(models, k, extra):
     assert r.stdout.decode() == c["out_text"]
 
 
+@pytest.mark.parametrize("extra", [["--device", "0,0"], ["--device", "0,0", "--streams", "1"], ["--streams", "3"]])
+def test_cli_device_list_and_streams(models, extra):
+    """Batches dealt to several contexts / devices in turn (the one GPU of the test box listed twice) come out in order."""
+    c = load_case("rna_default")
+    cmd = [BIN, "dtw", "--kmer-model", models[5], "--verbose", "0", "-K", "1", "--rna", *extra, c["fasta"], c["blow5"]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+    bad = subprocess.run([BIN, "dtw", "--kmer-model", models[5], "--device", "0;1", c["fasta"], c["blow5"]], capture_output=True)
+    assert bad.returncode != 0 and "comma separated" in bad.stderr.decode()
+
+
 def test_cli_errors_like_reference(models):
     c = load_case("dna_default")
     for extra, msg in ((["--dtw-std"], "only available for RNA"), (["-p", "-1"], "auto query start")):
