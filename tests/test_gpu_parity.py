@@ -320,6 +320,22 @@ def test_bad_query_window_is_rejected():
             al.align_events([t], [-1], [20])
 
 
+def test_context_lifecycle_does_not_leak():
+    """init / align / destroy in a loop: device memory returns to where it started."""
+    import torch
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=64, seed=3)
+    with S.Aligner(ref, flag) as al:
+        want = al.align_db(q, q_off)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        with S.Aligner(ref, flag) as al:
+            assert al.align_db(q, q_off).tobytes() == want.tobytes()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < 64 << 20, (free0, free1)
+
+
 def test_no_device_fallback_is_loud():
     ref = _small_ref(np.random.default_rng(0), [50], False)
     with pytest.raises(S.SfaError):
