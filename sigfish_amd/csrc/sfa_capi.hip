@@ -46,6 +46,13 @@ int fail(int code, const char *fmt, ...) {
                         __LINE__);                                                                  \
     } while (0)
 
+// after a kernel launch: a rejected launch (bad configuration, missing code object) is SFA_EKERNEL
+#define KERNEL_TRY()                                                                                            \
+    do {                                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                                      \
+        if (e_ != hipSuccess) return fail(SFA_EKERNEL, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
 // A device buffer that only ever grows (batches reuse it; nothing is allocated inside a steady-state call).
 struct DevBuf {
     void *p = nullptr;
@@ -336,23 +343,23 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
             launch_fill<true>(plan.max_R, std_dtw, da, st);
         else
             launch_fill<false>(plan.max_R, std_dtw, da, st);
-        HIP_TRY(hipGetLastError());
+        KERNEL_TRY();
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));
     fz.mode = plan.single_pass ? 0 : 1;
     hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
-    HIP_TRY(hipGetLastError());
+    KERNEL_TRY();
     HIP_TRY(hipEventRecord(c->ev[2], st));
     if (!plan.single_pass && n_quads > 0) {
         DpArgs ta = da;
         for (int i = 0; i < ta.n_cls; ++i) ta.cls[i].task_base = ta.cls[i].quad_base;  // one task per quad
         ta.n_tasks = n_quads;
         launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
-        HIP_TRY(hipGetLastError());
+        KERNEL_TRY();
         HIP_TRY(hipEventRecord(c->ev[3], st));
         fz.mode = 2;
         hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
-        HIP_TRY(hipGetLastError());
+        KERNEL_TRY();
     } else {
         HIP_TRY(hipEventRecord(c->ev[3], st));
     }
@@ -677,7 +684,7 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, st, ea);
     hipLaunchKernelGGL(sfa::ev_peaks_kernel, lane_grid, lane_block, 0, st, ea);
     hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, st, ea);
-    HIP_TRY(hipGetLastError());
+    KERNEL_TRY();
     std::vector<int32_t> nev(n);
     HIP_TRY(hipMemcpyAsync(nev.data(), c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -737,7 +744,7 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     sfa::BoundsArgs ba{c->e_evstart.as<int32_t>(), c->e_evlen.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(),
                        c->e_qoff.as<int64_t>(), c->e_b0.as<int32_t>(), c->e_b1.as<int32_t>(), c->e_b2.as<float>(), n};
     hipLaunchKernelGGL(sfa::ev_bounds_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ba);
-    HIP_TRY(hipGetLastError());
+    KERNEL_TRY();
     // the queries must be complete before align_device's uploads reuse the pinned staging area; same stream, in order
     if ((rc = align_device(c, c->d_queries.as<float>(), q_off.data(), n, c->d_out.as<ResultRow>()))) return rc;
     std::vector<int32_t> b0(n), b1(n);
