@@ -138,7 +138,7 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
  * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = qlen+16),
  * "waves_per_simd" (1..8, occupancy target used when splitting the contig list), "lane_widening" (0 = auto by batch
  * size, 1/2/4 = fixed: rows per lane / w and lanes per read * w, the small-batch latency shapes), "widen_below"
- * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 2), "min_slice_reads" (a batch whose
+ * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 5), "min_slice_reads" (a batch whose
  * checkpoints would not fit the budget at the shortest interval is cut into slices of at least this many reads, run
  * back to back; default 65536), "ev_parallel_prefix" (sfa_align_raw: 1 = wave-per-read prefix sums for every read
  * whose sums are provably exact in any order, the sequential kernel for the rest; 0 = sequential for all). */

@@ -314,8 +314,14 @@ int dtw_main(int argc, char **argv) {
     const int n_ctx = (o.streams > 0 ? o.streams : 2) * static_cast<int>(o.devices.size());
     std::vector<sfa_ctx_t *> ctxs(n_ctx, nullptr);
     for (int j = 0; j < n_ctx; ++j)
+    {
         if (sfa_init(&ctxs[j], &sref, o.flag, o.devices[j % o.devices.size()]) != SFA_OK)
             die(std::string("accelerator init failed: ") + sfa_last_error());
+        // the small-batch shapes pay off while ONE batch leaves the chip idle; with s batches in flight per device the
+        // threshold (waves per SIMD of a single batch) shrinks accordingly
+        const int per_dev = n_ctx / static_cast<int>(o.devices.size());
+        if (sfa_set_option(ctxs[j], "widen_below", std::max(1, 5 / per_dev)) != SFA_OK) die(sfa_last_error());
+    }
 
     if (o.flag & F_SAM) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
         for (int32_t i = 0; i < nref; ++i) fprintf(stdout, "@SQ\tSN:%s\tLN:%ld\n", contigs[i].name.c_str(), static_cast<long>(ref_len[i]));

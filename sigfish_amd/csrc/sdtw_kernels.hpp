@@ -379,18 +379,18 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     }
 }
 
-// Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill in the
-// throughput shapes (16 lanes per read).
-template <int R, bool TRACK, bool STD, bool STATIC_RQ, int I = 0>
+// Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill (worth
+// 5-20 % on the small-batch shapes, whose steps are short).
+template <int R, bool TRACK, bool STD, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
                                                const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T) {
-    if constexpr (TRACK || STD || R > 16 || !STATIC_RQ) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
+    if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
         sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
     } else {
         if (rq == I) {
             sweep_job<R, TRACK, STD, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, STATIC_RQ, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+            sweep_dispatch<R, TRACK, STD, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
         }
     }
 }
@@ -428,7 +428,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD, L == 16>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+        sweep_dispatch<R, TRACK, STD>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
     }
 
     if (g == lq && read >= 0) {

@@ -124,7 +124,7 @@ struct sfa_ctx {
     int64_t opt_ev_parallel_prefix = 1;      // sfa_align_raw: wave-per-read prefix sums where they are provably exact
     int64_t opt_min_slice_reads = 65536;     // a batch is only cut into slices of at least this many reads
     int64_t opt_lane_widening = 0;           // 0 = by batch size; 1, 2, 4 = fixed (rows per lane / w, lanes per read * w)
-    int64_t opt_widen_below = 2;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
+    int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
 

@@ -57,7 +57,7 @@ struct PlanParams {
     int64_t ckpt_budget_bytes = 32ll << 30;
     int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
     int64_t lane_widening = 0;      // 0 = auto (by batch size), else 1, 2 or 4
-    int64_t widen_below = 2;        // auto: widen (x4) when the batch has fewer than this many waves per SIMD
+    int64_t widen_below = 5;        // auto: widen (x4) when the batch has fewer than this many waves per SIMD
 };
 
 struct PlanClass {
@@ -151,8 +151,9 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         w = static_cast<int>(pp.lane_widening);
         if (w != 1) n_quads = layout(w);
     } else {
-        // measured (tools/small_batches.sh, nCoV, q = 250): below ~2 waves per SIMD a batch is latency-bound and the
-        // 4-rows-per-lane shapes halve its time; above, the 16-lane shapes are 25-40 % more efficient; x2 never wins
+        // measured (tools/small_batches.sh, nCoV, q = 250, profiles/r01_logs): up to ~5 waves per SIMD a batch is
+        // latency-bound and the 4-rows-per-lane shapes win (512 reads: 4.2 -> 2.0 ms, 4 096: 6.4 -> 5.2, 8 192: 10.2 ->
+        // 9.7); from ~6 on the 16-lane shapes do (3 % at 16 Ki reads, 14 % at 32 Ki); x2 is never the best
         if (static_cast<int64_t>(n_quads) * chunks_for(n_quads) < pp.widen_below * pp.n_sims) {
             w = 4;
             n_quads = layout(w);

@@ -163,13 +163,13 @@ def test_plan_batch_lane_widening():
     for s, per250 in ((s1, 4), (s2, 2), (s4, 1)):
         assert len(np.unique(s)) == len(s)
         assert ((s[:10] & 3) < per250).all()
-    # auto: a small batch widens fully, a big one does not (1024 SIMDs assumed, fewer than 2 waves per SIMD widens)
+    # auto: a small batch widens fully, a big one does not (1024 SIMDs assumed, fewer than 5 waves per SIMD widens)
     assert plan_batch(q_off, [29898, 29898])[0]["lane_widening"] == 4
     big = np.arange(0, 250 * 20001, 250, dtype=np.int64)
     assert plan_batch(big, [29898, 29898])[0]["lane_widening"] == 1
-    mid = np.arange(0, 250 * 4097, 250, dtype=np.int64)      # 1024 waves x 2 chunks = 2 per SIMD: stays
+    mid = np.arange(0, 250 * 10241, 250, dtype=np.int64)     # 2560 waves x 2 chunks = 5 per SIMD: stays
     assert plan_batch(mid, [29898, 29898])[0]["lane_widening"] == 1
-    assert plan_batch(mid[:2049], [29898, 29898])[0]["lane_widening"] == 4
+    assert plan_batch(mid[:8193], [29898, 29898])[0]["lane_widening"] == 4
     with pytest.raises(S.SfaError):
         plan_batch(q_off, [100], lane_widening=3)
 
