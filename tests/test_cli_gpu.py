@@ -75,6 +75,20 @@ def test_cli_device_list_and_streams(models, extra):
     assert bad.returncode != 0 and "comma separated" in bad.stderr.decode()
 
 
+def test_cli_empty_file_and_odd_batch_settings(models, tmp_path):
+    import sys
+    c = load_case("dna_default")
+    empty = str(tmp_path / "empty.blow5")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "make_blow5.py"), c["blow5"], empty, "--copies", "0"], check=True, capture_output=True)
+    for extra in ([], ["--host-events"]):
+        r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "0", *extra, c["fasta"], empty], capture_output=True, timeout=120)
+        assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()
+    for extra in (["-K", "100000"], ["-B", "1K"]):   # batch larger than the file; byte cap of one record
+        r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "0", *extra, c["fasta"], c["blow5"]], capture_output=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.decode() == c["out_text"], r.stderr.decode()
+
+
 def test_cli_errors_like_reference(models):
     c = load_case("dna_default")
     for extra, msg in ((["--dtw-std"], "only available for RNA"), (["-p", "-1"], "auto query start")):
