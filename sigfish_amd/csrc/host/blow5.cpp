@@ -23,25 +23,44 @@ bool take(const uint8_t *&p, const uint8_t *end, T *out) {
     return true;
 }
 
-bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> *dst) {
+// One zlib stream and one output buffer per thread, reused for every record (inflateInit2 allocates ~40 KB and a fresh
+// vector zero-fills its 64 KB: together a fifth of the cost of decoding a 4 KB record).  The buffer only grows and
+// keeps its size; *len receives the number of bytes produced.
+struct Inflater {
     z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, MAX_WBITS) != Z_OK) return false;
-    dst->resize(std::max<size_t>(n * 4, 1 << 16));
+    bool ready = false;
+    std::vector<uint8_t> buf;
+    ~Inflater() {
+        if (ready) inflateEnd(&zs);
+    }
+};
+
+bool inflate_all(const uint8_t *src, size_t n, const uint8_t **out, size_t *len) {
+    thread_local Inflater inf;
+    if (!inf.ready) {
+        memset(&inf.zs, 0, sizeof inf.zs);
+        if (inflateInit2(&inf.zs, MAX_WBITS) != Z_OK) return false;
+        inf.ready = true;
+        inf.buf.resize(1 << 16);
+    } else if (inflateReset(&inf.zs) != Z_OK) {
+        return false;
+    }
+    if (inf.buf.size() < n * 4) inf.buf.resize(n * 4);
+    z_stream &zs = inf.zs;
     zs.next_in = const_cast<Bytef *>(src);
     zs.avail_in = static_cast<uInt>(n);
     size_t have = 0;
     int rc;
     do {
-        if (have == dst->size()) dst->resize(dst->size() * 2);
-        zs.next_out = dst->data() + have;
-        zs.avail_out = static_cast<uInt>(dst->size() - have);
+        if (have == inf.buf.size()) inf.buf.resize(inf.buf.size() * 2);
+        zs.next_out = inf.buf.data() + have;
+        zs.avail_out = static_cast<uInt>(inf.buf.size() - have);
         rc = inflate(&zs, Z_NO_FLUSH);
-        have = dst->size() - zs.avail_out;
+        have = inf.buf.size() - zs.avail_out;
     } while (rc == Z_OK);
-    inflateEnd(&zs);
     if (rc != Z_STREAM_END) return false;
-    dst->resize(have);
+    *out = inf.buf.data();
+    *len = have;
     return true;
 }
 
@@ -242,15 +261,16 @@ bool Blow5Reader::parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::
 
 bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const {
     rec->record_bytes = size;
-    std::vector<uint8_t> inflated;
     const uint8_t *p = mem, *end = p + size;
     if (record_press_ == 1) {
-        if (!inflate_all(mem, size, &inflated)) {
+        const uint8_t *inflated = nullptr;  // this thread's buffer, valid until its next record
+        size_t inflated_len = 0;
+        if (!inflate_all(mem, size, &inflated, &inflated_len)) {
             *err = "malformed BLOW5: record does not inflate";
             return false;
         }
-        p = inflated.data();
-        end = p + inflated.size();
+        p = inflated;
+        end = p + inflated_len;
     }
     uint16_t idlen;
     uint64_t len;
