@@ -250,63 +250,79 @@ struct PeakDet32 {  // PeakDet with 32-bit positions (a read has < 2^31 samples)
     bool valid;
 };
 
+// TWO LANES PER READ: the even lane runs the short detector, the odd lane the long one, so the wave executes the state
+// machine once per sample instead of twice (its branches diverge anyway) and covers 32 reads.  The detectors are
+// coupled one way -- at sample j the short one may mask the long one before the long one looks at j -- so the odd lane
+// runs ONE SAMPLE BEHIND: in iteration m the short detector handles sample m, the long one sample m-1, and the short
+// lane's mask for sample m reaches the long lane (one DPP move) after that.  The reference's order of side effects,
+// S(0) L(0) S(1) L(1) ..., becomes L(m-1) S(m) inside an iteration; both lanes keep identical copies of the event
+// counter and of the open event's start, exchanging their peaks with a second DPP move.
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true); }
+
 __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
-    __shared__ float t_t[2][64][kEvTile + 1];
-    __shared__ int64_t lds_b[64];
-    __shared__ int32_t lds_n[64];
+    __shared__ float t_t[2][32][kEvTile + 1];
+    __shared__ int64_t lds_b[32];
+    __shared__ int32_t lds_n[32];
     const int lane = threadIdx.x;
-    const int i = blockIdx.x * 64 + lane;
-    bool live;
-    int64_t b;
-    int32_t n;
-    TileReads tr;
-    tr.load(a, lane, lds_b, lds_n, &live, &b, &n);
+    const int r = lane >> 1, k = lane & 1;  // read of the block, detector
+    const int i = blockIdx.x * 32 + r;
+    const bool live = i < a.n_reads;
+    if (lane < 32) {
+        const int ii = blockIdx.x * 32 + lane;
+        const bool lv = ii < a.n_reads;
+        const int64_t bb = a.raw_off[lv ? ii : a.n_reads - 1];
+        lds_b[lane] = bb;
+        lds_n[lane] = lv ? static_cast<int32_t>(a.raw_off[ii + 1] - bb) : 0;
+    }
+    __syncthreads();
+    const int32_t n = lds_n[r];
+    int maxn = n;
+    for (int o = 32; o; o >>= 1) maxn = max(maxn, __shfl_xor(maxn, o));
+    const int64_t b0 = lds_b[0];
+    const int half = lane >> 5, jl = lane & 31;
+    uint32_t rel[16];
+    int32_t len[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {  // cooperative phase: iteration `it` of a half-wave covers read 2*it + half
+        rel[it] = static_cast<uint32_t>(lds_b[2 * it + half] - b0);
+        len[it] = lds_n[2 * it + half];
+    }
     const int64_t eo = live ? a.ev_off[i] : 0;
     const int ecap = live ? static_cast<int>(a.ev_off[i + 1] - eo) : 0;
     int32_t *evs = a.ev_start + eo;
-    const float *t1p = a.t1 + tr.b0, *t2p = a.t2 + tr.b0;
-    PeakDet32 d[2];
-    d[0] = PeakDet32{a.thr1, a.w1, 0, -1, 3.402823466e+38f, false};
-    d[1] = PeakDet32{a.thr2, a.w2, 0, -1, 3.402823466e+38f, false};
-    int nev = 0, last = 0;  // events opened so far, start of the open event
-    const int half = lane >> 5, jl = lane & 31;
+    const float *t1p = a.t1 + b0, *t2p = a.t2 + b0;
+    PeakDet32 p = k ? PeakDet32{a.thr2, a.w2, 0, -1, 3.402823466e+38f, false} : PeakDet32{a.thr1, a.w1, 0, -1, 3.402823466e+38f, false};
+    int nev = 0, last = 0;  // events opened so far, start of the open event (same in both lanes of a pair)
+    float carry = 0.0f;     // the long detector's sample from the previous tile
     // all loads of a tile in flight together; the next tile is fetched while the detectors walk this one
-    float v0[32], v1[32];
+    float v0[16], v1[16];
     auto fetch = [&](int base) {
         const int bj = base + jl;
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
-            const uint32_t o = bj < tr.len[it] ? tr.rel[it] + static_cast<uint32_t>(bj) : 0u;
+        for (int it = 0; it < 16; ++it) {
+            const uint32_t o = bj < len[it] ? rel[it] + static_cast<uint32_t>(bj) : 0u;
             v0[it] = t1p[o];
             v1[it] = t2p[o];
         }
     };
     fetch(0);
-    for (int base = 0; base < tr.maxn; base += kEvTile) {
+    for (int base = 0; base < maxn + 1; base += kEvTile) {  // + 1: the long detector's last sample
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
+        for (int it = 0; it < 16; ++it) {
             t_t[0][2 * it + half][jl] = v0[it];
             t_t[1][2 * it + half][jl] = v1[it];
         }
-        if (base + kEvTile < tr.maxn) fetch(base + kEvTile);
+        if (base + kEvTile < maxn + 1) fetch(base + kEvTile);
         __syncthreads();
-        const int cnt = min(kEvTile, n - base);
-        float c0[kEvTile], c1[kEvTile];  // this lane's row of the tile
+        float c[kEvTile];  // this lane's statistic over the tile
+#pragma unroll
+        for (int jj = 0; jj < kEvTile; ++jj) c[jj] = t_t[k][r][jj];
 #pragma unroll
         for (int jj = 0; jj < kEvTile; ++jj) {
-            c0[jj] = t_t[0][lane][jj];
-            c1[jj] = t_t[1][lane][jj];
-        }
-        // (a select-only formulation of the state machine was measured 25 % slower than these branches)
-#pragma unroll
-        for (int jj = 0; jj < kEvTile; ++jj) {
-            if (jj >= cnt) continue;
-            const int j = base + jj;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                PeakDet32 &p = d[k];
-                if (p.masked_to >= j) continue;
-                const float cur = k ? c1[jj] : c0[jj];
+            const int j = base + jj - k;  // the sample this lane looks at
+            const float cur = k ? (jj ? c[jj ? jj - 1 : 0] : carry) : c[jj];
+            int peak = -1, mask_to = -1;  // what this lane's detector did: a peak to emit, a mask for the long detector
+            if (j >= 0 && j < n && p.masked_to < j) {
                 if (p.peak_pos == -1) {
                     if (cur < p.peak_value) {
                         p.peak_value = cur;
@@ -319,30 +335,39 @@ __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
                         p.peak_value = cur;
                         p.peak_pos = j;
                     }
-                    if (k == 0 && p.peak_value > p.threshold) {  // the short detector masks the long one
-                        d[1].masked_to = p.peak_pos + p.window;
-                        d[1].peak_pos = -1;
-                        d[1].peak_value = 3.402823466e+38f;
-                        d[1].valid = false;
-                    }
+                    if (k == 0 && p.peak_value > p.threshold) mask_to = p.peak_pos + p.window;  // the short detector masks the long one
                     if (p.peak_value - cur > a.peak_height && p.peak_value > p.threshold) p.valid = true;
                     if (p.valid && (j - p.peak_pos) > p.window / 2) {
-                        const int pk = p.peak_pos;
-                        if (pk > 0 && pk < n && nev < ecap) {  // create_events() skips peaks at 0 / >= n
-                            evs[nev] = last;
-                            ++nev;
-                            last = pk;
-                        }
+                        if (p.peak_pos > 0 && p.peak_pos < n) peak = p.peak_pos;  // create_events() skips peaks at 0 / >= n
                         p.peak_pos = -1;
                         p.peak_value = cur;
                         p.valid = false;
                     }
                 }
             }
+            const int other_peak = pair_swap(peak), other_mask = pair_swap(mask_to);
+            const int peak_long = k ? peak : other_peak, peak_short = k ? other_peak : peak;
+            if (peak_long >= 0 && nev < ecap) {  // L(m-1) comes before S(m)
+                if (k == 1) evs[nev] = last;
+                ++nev;
+                last = peak_long;
+            }
+            if (peak_short >= 0 && nev < ecap) {
+                if (k == 0) evs[nev] = last;
+                ++nev;
+                last = peak_short;
+            }
+            if (k == 1 && other_mask >= 0) {  // the short detector's mask for its sample m = j + 1, before the long one gets there
+                p.masked_to = other_mask;
+                p.peak_pos = -1;
+                p.peak_value = 3.402823466e+38f;
+                p.valid = false;
+            }
         }
+        carry = c[kEvTile - 1];
         __syncthreads();
     }
-    if (!live) return;
+    if (!live || k != 0) return;
     if (nev > 0 && nev < ecap) {  // the last event runs to the end of the signal; no peak at all -> no events
         evs[nev] = last;
         ++nev;

@@ -682,7 +682,7 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     if (ea.use_flags) hipLaunchKernelGGL(sfa::ev_prefix_par_kernel, dim3(n), dim3(64), 0, st, ea);  // flags what it cannot do exactly
     hipLaunchKernelGGL(sfa::ev_prefix_kernel, lane_grid, lane_block, 0, st, ea);
     hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, st, ea);
-    hipLaunchKernelGGL(sfa::ev_peaks_kernel, lane_grid, lane_block, 0, st, ea);
+    hipLaunchKernelGGL(sfa::ev_peaks_kernel, dim3((n + 31) / 32), dim3(64), 0, st, ea);  // two lanes per read
     hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, st, ea);
     KERNEL_TRY();
     std::vector<int32_t> nev(n);

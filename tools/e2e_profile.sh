@@ -15,7 +15,7 @@ PY
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/e2e_prof_K$K
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o runc -- $ROOT/sigfish_amd/bin/sigfish-amd dtw --kmer-model /tmp/syn6.model -t 16 -K $K -B 2G --verbose 3 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o runc -- $ROOT/sigfish_amd/bin/sigfish-amd dtw --kmer-model /tmp/syn6.model -t 16 -K $K -B 2G --streams 1 --verbose 3 \
     tests/golden/data/nCoV-2019.reference.fasta /tmp/big.blow5 > /tmp/big.paf 2> $OUT/log.txt
 grep dtw_main $OUT/log.txt
 cut -d, -f1-4 $OUT/runc_kernel_stats.csv | head -14
