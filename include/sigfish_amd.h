@@ -243,6 +243,11 @@ const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key); /* header attribute
 int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const int16_t **raw, int64_t *n_raw);
 void sfa_blow5_close(sfa_blow5_t *f);
 
+/* The record decompressor of the BLOW5 reader on its own: inflates the zlib stream in[0..n) into out[0..cap) with the
+ * library's own DEFLATE decoder and returns the number of bytes produced, SFA_ERANGE when cap is too small, SFA_EINVAL
+ * when the decoder declines the stream (the reader then falls back to zlib's inflate). */
+int64_t sfa_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,8 @@
 // like a reference binary built without zstd=1).
 #include "blow5.hpp"
 
+#include "inflate.hpp"
+
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <immintrin.h>
@@ -37,6 +39,10 @@ struct Inflater {
 
 bool inflate_all(const uint8_t *src, size_t n, const uint8_t **out, size_t *len) {
     thread_local Inflater inf;
+    if (fast_inflate_zlib(src, n, &inf.buf, len)) {  // own decoder (inflate.hpp); anything it declines goes to zlib
+        *out = inf.buf.data();
+        return true;
+    }
     if (!inf.ready) {
         memset(&inf.zs, 0, sizeof inf.zs);
         if (inflateInit2(&inf.zs, MAX_WBITS) != Z_OK) return false;

@@ -12,6 +12,7 @@
 #include "../../include/sigfish_amd.h"
 #include "sfa_plan.hpp"
 #include "host/blow5.hpp"
+#include "host/inflate.hpp"
 #include "host/events.hpp"
 #include "host/refio.hpp"
 #include "host/sam.hpp"
@@ -247,5 +248,15 @@ int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const i
 }
 
 void sfa_blow5_close(sfa_blow5_t *f) { delete f; }
+
+int64_t sfa_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap) {
+    if (!in || (!out && cap)) return SFA_EINVAL;
+    thread_local std::vector<uint8_t> buf;
+    size_t len = 0;
+    if (!sfa::fast_inflate_zlib(in, n, &buf, &len)) return SFA_EINVAL;
+    if (len > cap) return SFA_ERANGE;
+    if (len) memcpy(out, buf.data(), len);
+    return static_cast<int64_t>(len);
+}
 
 }  // extern "C"
