@@ -243,6 +243,9 @@ const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key); /* header attribute
 int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const int16_t **raw, int64_t *n_raw);
 void sfa_blow5_close(sfa_blow5_t *f);
 
+/* Free and total memory of a device in bytes (hipMemGetInfo), for callers sizing their batches. */
+int sfa_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
 /* The record decompressor of the BLOW5 reader on its own: inflates the zlib stream in[0..n) into out[0..cap) with the
  * library's own DEFLATE decoder and returns the number of bytes produced, SFA_ERANGE when cap is too small, SFA_EINVAL
  * when the decoder declines the stream (the reader then falls back to zlib's inflate). */

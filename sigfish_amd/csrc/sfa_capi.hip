@@ -136,7 +136,7 @@ struct sfa_ctx {
 
     // per-batch scratch
     DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_wscore, d_tst, d_ck, d_out;
-    PinBuf h_stage, h_out;
+    PinBuf h_stage, h_out, h_small;
 
     // raw-signal path (sfa_align_raw)
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
@@ -489,6 +489,7 @@ void sfa_destroy(sfa_ctx_t *c) {
         b->release();
     c->h_stage.release();
     c->h_out.release();
+    c->h_small.release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -685,8 +686,9 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     hipLaunchKernelGGL(sfa::ev_peaks_kernel, dim3((n + 31) / 32), dim3(64), 0, st, ea);  // two lanes per read
     hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, st, ea);
     KERNEL_TRY();
-    std::vector<int32_t> nev(n);
-    HIP_TRY(hipMemcpyAsync(nev.data(), c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    if ((rc = c->h_small.reserve(16 * (size_t)n))) return rc;  // page-locked: event counts, then the three raw-coordinate columns
+    int32_t *nev = c->h_small.as<int32_t>();
+    HIP_TRY(hipMemcpyAsync(nev, c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 
     // query windows on the host (normalise_single, src/sigfish.c:433-480); the arithmetic part runs on the device
@@ -747,12 +749,12 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     KERNEL_TRY();
     // the queries must be complete before align_device's uploads reuse the pinned staging area; same stream, in order
     if ((rc = align_device(c, c->d_queries.as<float>(), q_off.data(), n, c->d_out.as<ResultRow>()))) return rc;
-    std::vector<int32_t> b0(n), b1(n);
-    std::vector<float> b2(n);
+    int32_t *b0 = c->h_small.as<int32_t>(), *b1 = b0 + n;
+    float *b2 = reinterpret_cast<float *>(b1 + n);
     HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_out.p, sizeof(sfa_result_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(b0.data(), c->e_b0.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(b1.data(), c->e_b1.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(b2.data(), c->e_b2.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b0, c->e_b0.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b1, c->e_b1.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(b2, c->e_b2.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     memcpy(rows, c->h_out.p, sizeof(sfa_result_t) * (size_t)n);
     for (int32_t i = 0; i < n; ++i) {
@@ -760,6 +762,16 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
         info[i].end_raw_idx = static_cast<uint64_t>(static_cast<float>(static_cast<uint64_t>(b1[i])) + b2[i]);  // u64 + float, as in C
     }
     return resolve_profile(c);
+}
+
+int sfa_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(SFA_EINVAL, "sfa_device_memory: null argument");
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return SFA_OK;
 }
 
 void *sfa_pinned_alloc(size_t bytes) {

@@ -322,17 +322,22 @@ def test_bad_query_window_is_rejected():
 
 def test_context_lifecycle_does_not_leak():
     """init / align / destroy in a loop: device memory returns to where it started."""
-    import torch
+    import ctypes as C
+    from sigfish_amd import _lib
+
+    def free_bytes():
+        f, t = C.c_uint64(), C.c_uint64()
+        assert _lib.load().sfa_device_memory(0, C.byref(f), C.byref(t)) == 0
+        return f.value
+
     ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=64, seed=3)
     with S.Aligner(ref, flag) as al:
         want = al.align_db(q, q_off)
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    free0 = free_bytes()
     for _ in range(40):
         with S.Aligner(ref, flag) as al:
             assert al.align_db(q, q_off).tobytes() == want.tobytes()
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    free1 = free_bytes()
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
 
 
