@@ -15,9 +15,9 @@
 //     events), kept in VGPRs together with their running cost.  No barriers, no cost matrix.  Queries longer
 //     than 512 events take 32 or 64 lanes per read at R = 32 (two reads / one read per wave, up to 1024 / 2048
 //     events); everything below is written for L lanes per read.  SMALL BATCHES use the same freedom the other
-//     way round: when there are too few reads to fill the chip the planner halves or quarters R and doubles or
-//     quadruples L (q = 250: 8 rows x 32 lanes or 4 rows x 64 lanes), which gives 2-4x the waves, each with
-//     a 2-4x shorter step -- latency per batch drops accordingly.
+//     way round: when there are too few reads to fill the chip the planner quarters R and quadruples L
+//     (q = 250: 4 rows x 64 lanes; halving / doubling is an option), which gives 4x the waves, each with a 4x
+//     shorter step -- latency per batch drops accordingly.
 //   * the lanes of a row walk an anti-diagonal: at step t lane g is at reference column t-g, so the only
 //     cross-lane traffic per step is ONE value per lane, the bottom cost handed to the next lane (through a
 //     wave-private LDS window, see Exchange): the neighbour's value from the previous step is this lane's "up",
@@ -28,7 +28,7 @@
 //     few hundred KB).
 //   * TWO PASSES.  Pass 1 (sdtw_fill_kernel, >95 % of the time) evaluates costs only -- v_sub, v_min3,
 //     v_add(|d|) per cell -- finds every window minimum and the per-read top-2, and drops a checkpoint of the
-//     (R+1)-register anti-diagonal state every T steps.  Pass 2 (sdtw_trace_kernel) re-runs, for each read's
+//     (R+1)-register anti-diagonal state (plus the step index) every T steps.  Pass 2 (sdtw_trace_kernel) re-runs, for each read's
 //     WINNING candidate only, the few hundred steps between a checkpoint and the winning cell with start-column
 //     tracking switched on (+2 v_cmp_eq, +2 v_cndmask per cell); if the path turns out to begin before the
 //     checkpoint (start sentinel -1 survives) it backs off to an earlier one, ultimately to step 0.  Costs are
