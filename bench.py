@@ -6,8 +6,9 @@
 
 Workload (config.workload = "ncov_r9_dna_q250", BASELINE.json configs[2]): synthetic R9 DNA reads (250 events,
 5 % shorter) against the 29 903 b nCoV-2019 reference, both strands, -q 250.  A "step" is one pass of the hot
-path (sfa_align_batch_device: plan + fill kernels + finalize kernel) over one batch of --reads reads per GPU whose
-query events are already resident in HBM, plus (N > 1) the gather of result rows to rank 0 over RCCL.  Reads shard
+path (sfa_align_batch_device: plan + fill kernel + finalize + trace kernel + finalize) over one batch of --reads reads
+per GPU whose query events are already resident in HBM; for N > 1 the rows of all timed steps are gathered to rank 0
+over RCCL once, after the last step and inside the timed region.  Reads shard
 across ranks with no data-path collective (weak scaling: every rank gets --reads reads); the reference event model
 is broadcast once, before the timed region.
 
