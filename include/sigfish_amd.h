@@ -202,6 +202,12 @@ typedef struct {
 int sfa_align_raw(sfa_ctx_t *ctx, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n_reads,
                   int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info);
 
+/* Same, and the event table of every read's query window comes back as well: query_events[i * query_size + e], e <
+ * info[i].qend - info[i].qstart, holds event qstart + e of read i with its mean z-normalised -- what sfa_sam_row needs
+ * (pass it with qstart = 0, qend = the window length).  query_events may be NULL (then identical to sfa_align_raw). */
+int sfa_align_raw_ex(sfa_ctx_t *ctx, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n_reads,
+                  int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_event_t *query_events);
+
 /* Page-locked host memory for the buffers handed to sfa_align_raw / sfa_align_batch (uploads from pageable memory
  * run at a fraction of the PCIe rate).  Plain malloc-style pair; NULL on failure. */
 void *sfa_pinned_alloc(size_t bytes);

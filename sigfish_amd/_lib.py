@@ -45,7 +45,7 @@ class SfaEvent(C.Structure):
 
 
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
+SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close", "sfa_inflate_zlib", "sfa_device_memory"]
@@ -70,6 +70,7 @@ def load():
     L.sfa_align_batch_device.argtypes = [vp, vp, i64p, C.c_int32, vp, C.c_int]
     L.sfa_align_events.argtypes = [vp, C.POINTER(C.POINTER(SfaEvent)), i64p, i64p, i64p, C.c_int32, vp]
     L.sfa_align_raw.argtypes = [vp, C.POINTER(C.c_int16), i64p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, vp, vp]
+    L.sfa_align_raw_ex.argtypes = [vp, C.POINTER(C.c_int16), i64p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     L.sfa_pinned_alloc.argtypes = [C.c_size_t]
     L.sfa_pinned_alloc.restype = vp
     L.sfa_pinned_free.argtypes = [vp]

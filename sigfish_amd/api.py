@@ -216,9 +216,10 @@ class Aligner:
     def set_option(self, key, value):
         _check(self._L.sfa_set_option(self._h, key.encode(), int(value)), f"sfa_set_option({key})")
 
-    def align_raw(self, raw, raw_off, scaling, prefix_size=50, query_size=250):
+    def align_raw(self, raw, raw_off, scaling, prefix_size=50, query_size=250, return_events=False):
         """process_db on the device: raw int16 samples (concatenated) -> (rows, info).  scaling: float64 [n,3] =
-        digitisation, offset, range per read."""
+        digitisation, offset, range per read.  return_events: also the query windows' event tables,
+        EVENT_DTYPE[n, query_size] (means z-normalised; read i uses the first info.qend - info.qstart entries)."""
         raw = np.ascontiguousarray(raw, np.int16)
         ro = np.ascontiguousarray(raw_off, np.int64)
         sc = np.ascontiguousarray(scaling, np.float64).reshape(-1)
@@ -227,10 +228,12 @@ class Aligner:
         info = np.zeros(n, QUERY_INFO_DTYPE)
         if raw.size == 0:
             raw = np.zeros(1, np.int16)
-        _check(self._L.sfa_align_raw(self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), ro.ctypes.data_as(_lib.i64p),
-                                     sc.ctypes.data_as(C.POINTER(C.c_double)), n, prefix_size, query_size,
-                                     rows.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p)), "sfa_align_raw")
-        return rows, info
+        qev = np.zeros((n, query_size), EVENT_DTYPE) if return_events else None
+        _check(self._L.sfa_align_raw_ex(self._h, raw.ctypes.data_as(C.POINTER(C.c_int16)), ro.ctypes.data_as(_lib.i64p),
+                                        sc.ctypes.data_as(C.POINTER(C.c_double)), n, prefix_size, query_size,
+                                        rows.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p),
+                                        qev.ctypes.data_as(C.c_void_p) if return_events else None), "sfa_align_raw_ex")
+        return (rows, info, qev) if return_events else (rows, info)
 
     def sync(self):
         _check(self._L.sfa_sync(self._h), "sfa_sync")

@@ -428,6 +428,35 @@ __global__ void __launch_bounds__(64) ev_query_kernel(const QueryArgs a) {
     for (int64_t j = 0; j < len; ++j) a.queries[o + j] = (m[j] - mean) / sd;
 }
 
+// The query window's event table in the layout of event_t / sfa_event_t (src/sigfish.h:57-64), means z-normalised, for
+// hosts that need it (SAM output rebuilds the warp path and the signal segments from it).  One block per read.
+struct PackArgs {
+    const int32_t *ev_start;
+    const float *ev_length, *ev_stdv;
+    const int64_t *ev_off;
+    const int64_t *qstart;
+    const int64_t *q_off;
+    const float *queries;  // normalised means, packed at q_off
+    uint64_t *out;         // [n][query_size] records of 24 bytes: u64 start, f32 length, mean, stdv, pad
+    int32_t query_size;
+};
+
+__global__ void __launch_bounds__(128) ev_pack_events_kernel(const PackArgs a) {
+    const int i = blockIdx.x;
+    const int64_t o = a.q_off[i], len = a.q_off[i + 1] - o;
+    const int64_t e0 = a.ev_off[i] + a.qstart[i];
+    char *dst = reinterpret_cast<char *>(a.out) + static_cast<int64_t>(i) * a.query_size * 24;
+    for (int64_t e = threadIdx.x; e < len; e += 128) {
+        char *rec = dst + e * 24;
+        *reinterpret_cast<uint64_t *>(rec) = static_cast<uint64_t>(a.ev_start[e0 + e]);
+        float *f = reinterpret_cast<float *>(rec + 8);
+        f[0] = a.ev_length[e0 + e];
+        f[1] = a.queries[o + e];
+        f[2] = a.ev_stdv[e0 + e];
+        f[3] = 0.0f;
+    }
+}
+
 // raw-signal coordinates of the query for the PAF columns 3-4 (aln_to_str, src/sigfish.c:800-805)
 struct BoundsArgs {
     const int32_t *ev_start;

@@ -345,11 +345,14 @@ int dtw_main(int argc, char **argv) {
         std::vector<int64_t> raw_off;
         std::vector<double> scaling;
         std::vector<sfa_query_info_t> info;
+        std::vector<sfa_event_t> qev;  // [n][query] event tables of the query windows (SAM with device-side events)
         int32_t n = 0;
         int64_t bytes = 0;
     };
-    // events on the GPU unless SAM (needs the event tables on the host) or the RNA auto prefix (adaptor/poly-A on host)
-    const bool gpu_events = !o.host_events && !(o.flag & F_SAM) && o.prefix >= 0;
+    // events on the GPU unless the RNA auto prefix is asked for (adaptor/poly-A detection stays on the host); for SAM the
+    // event tables of the query windows come back from the device with the rows
+    const bool gpu_events = !o.host_events && o.prefix >= 0;
+    const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);
     for (Slot &sl : slots) {
@@ -367,8 +370,9 @@ int dtw_main(int argc, char **argv) {
         const double a = realtime();
         if (gpu_events) {
             sl.info.resize(n);
-            if (n > 0 && sfa_align_raw(ctx, sl.raw, sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
-                                       sl.info.data()) != SFA_OK)
+            if (sam) sl.qev.resize(static_cast<size_t>(n) * o.query);
+            if (n > 0 && sfa_align_raw_ex(ctx, sl.raw, sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
+                                          sl.info.data(), sam ? sl.qev.data() : nullptr) != SFA_OK)
                 die(std::string("alignment failed: ") + sfa_last_error());
         } else if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK) {
             die(std::string("alignment failed: ") + sfa_last_error());
@@ -394,15 +398,18 @@ int dtw_main(int argc, char **argv) {
             pool.run(n, [&](int64_t i) {
                 const Read &r = batch[i];
                 const sfa_result_t &row = rows[i];
-                if (!r.keep || !row.valid || row.rid < 0) return;
+                if (!row.valid || row.rid < 0 || (!gpu_events && !r.keep)) return;
+                // the event table and the window inside it: the read's own (host events) or the window alone (device events)
+                const sfa_event_t *ev = gpu_events ? sl.qev.data() + static_cast<size_t>(i) * o.query : r.ev.data();
+                const int64_t qs = gpu_events ? 0 : r.qstart, qe = gpu_events ? sl.info[i].qend - sl.info[i].qstart : r.qend;
                 const float *y = row.strand == '+' ? fwd[row.rid].data() : rev[row.rid].data();
                 std::string buf(1 << 16, '\0');
-                int len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
-                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
+                int len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), ev, qs, qe, y,
+                                      ref_len[row.rid], ref_off[row.rid], o.flag);
                 if (len == SFA_ERANGE) {  // very long ss strings (full-reference alignments)
                     buf.assign(1 << 22, '\0');
-                    len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), r.ev.data(), r.qstart,
-                                      r.qend, y, ref_len[row.rid], ref_off[row.rid], o.flag);
+                    len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), ev, qs, qe, y,
+                                      ref_len[row.rid], ref_off[row.rid], o.flag);
                 }
                 if (len > 0) sam[i].assign(buf.data(), len);
             });

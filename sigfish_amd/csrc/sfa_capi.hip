@@ -140,7 +140,7 @@ struct sfa_ctx {
 
     // raw-signal path (sfa_align_raw)
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
-        e_qoff, e_b0, e_b1, e_b2, e_flag;
+        e_qoff, e_b0, e_b1, e_b2, e_flag, e_qev;
 
     sfa_profile_t prof{};
     bool prof_pending = false;
@@ -485,7 +485,7 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev})
         b->release();
     c->h_stage.release();
     c->h_out.release();
@@ -617,6 +617,11 @@ int sfa_align_events(sfa_ctx_t *c, const sfa_event_t *const *events, const int64
 
 int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n, int32_t prefix_size,
                   int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info) {
+    return sfa_align_raw_ex(c, raw, raw_off, scaling, n, prefix_size, query_size, rows, info, nullptr);
+}
+
+int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n, int32_t prefix_size,
+                     int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_event_t *query_events) {
     if (!c || n < 0 || (n > 0 && (!raw || !raw_off || !scaling || !rows || !info))) return fail(SFA_EINVAL, "sfa_align_raw: bad argument");
     if (prefix_size < 0) return fail(SFA_EINVAL, "sfa_align_raw: automatic query start (-p -1) needs the host stages");
     if (query_size <= 0) return fail(SFA_EINVAL, "sfa_align_raw: query_size must be positive");
@@ -746,6 +751,15 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     sfa::BoundsArgs ba{c->e_evstart.as<int32_t>(), c->e_evlen.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(),
                        c->e_qoff.as<int64_t>(), c->e_b0.as<int32_t>(), c->e_b1.as<int32_t>(), c->e_b2.as<float>(), n};
     hipLaunchKernelGGL(sfa::ev_bounds_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ba);
+    if (query_events) {  // the query windows' event tables, for SAM output on the host
+        static_assert(sizeof(sfa_event_t) == 24, "event record layout");
+        const size_t qe_bytes = sizeof(sfa_event_t) * static_cast<size_t>(n) * static_cast<size_t>(query_size);
+        if ((rc = c->e_qev.reserve(qe_bytes))) return rc;
+        sfa::PackArgs pa{c->e_evstart.as<int32_t>(), c->e_evlen.as<float>(), c->e_evstdv.as<float>(), c->e_evoff.as<int64_t>(),
+                         c->e_qstart.as<int64_t>(), c->e_qoff.as<int64_t>(), c->d_queries.as<float>(), c->e_qev.as<uint64_t>(), query_size};
+        hipLaunchKernelGGL(sfa::ev_pack_events_kernel, dim3(n), dim3(128), 0, st, pa);
+        HIP_TRY(hipMemcpyAsync(query_events, c->e_qev.p, qe_bytes, hipMemcpyDeviceToHost, st));
+    }
     KERNEL_TRY();
     // the queries must be complete before align_device's uploads reuse the pinned staging area; same stream, in order
     if ((rc = align_device(c, c->d_queries.as<float>(), q_off.data(), n, c->d_out.as<ResultRow>()))) return rc;

@@ -114,3 +114,23 @@ def test_parallel_prefix_sums_and_their_fallback():
         meta = dict(digitisation=scs[k][0], offset=scs[k][1], range=scs[k][2])
         ev = S.detect_events(raws[k], meta, False)
         assert info_par["n_events"][k] == len(ev)
+
+
+def test_query_window_events_come_back_for_sam():
+    """sfa_align_raw_ex: the event tables of the query windows (means z-normalised) equal the host stages' tables."""
+    c = load_case("dna_default")
+    ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
+    ids, raw, off, scal = _load_raw(c["blow5"])
+    with S.Aligner(ref, 0) as al:
+        rows, info, qev = al.align_raw(raw, off, scal, 50, 250, return_events=True)
+        rows2, info2 = al.align_raw(raw, off, scal, 50, 250)
+    assert rows.tobytes() == rows2.tobytes() and info.tobytes() == info2.tobytes()
+    for i in range(len(ids)):
+        r = raw[off[i]:off[i + 1]]
+        meta = dict(digitisation=scal[i][0], offset=scal[i][1], range=scal[i][2])
+        ev = S.detect_events(r, meta, False)
+        keep, a, b = S.select_query(ev, r, meta, 50, 250, 0, 0)   # normalises ev[a:b].mean in place
+        assert keep and (a, b) == (info["qstart"][i], info["qend"][i])
+        got = qev[i][:b - a]
+        for f in ("start", "length", "mean", "stdv"):
+            assert np.array_equal(got[f], ev[f][a:b]), (i, f)
