@@ -341,6 +341,19 @@ def test_context_lifecycle_does_not_leak():
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
 
 
+def test_options_are_validated():
+    ref = _small_ref(np.random.default_rng(0), [50], False)
+    with S.Aligner(ref, 0) as al:
+        for key, bad in (("ckpt_interval", 3), ("ckpt_interval", 48), ("ckpt_budget_bytes", -1), ("waves_per_simd", 0),
+                         ("waves_per_simd", 9), ("lane_widening", 3), ("widen_below", -1), ("min_slice_reads", 0),
+                         ("no_such_option", 1)):
+            with pytest.raises(S.SfaError):
+                al.set_option(key, bad)
+        for key, ok in (("ckpt_interval", 0), ("ckpt_interval", 64), ("single_pass", 1), ("single_pass", 0), ("trace_margin", -1),
+                        ("lane_widening", 0), ("widen_below", 5), ("ev_parallel_prefix", 0), ("ev_parallel_prefix", 1)):
+            al.set_option(key, ok)
+
+
 def test_no_device_fallback_is_loud():
     ref = _small_ref(np.random.default_rng(0), [50], False)
     with pytest.raises(S.SfaError):
