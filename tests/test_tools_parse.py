@@ -22,17 +22,17 @@ def test_shell_tools_parse():
 
 
 def test_blow5_writer_round_trips(tmp_path):
-    """tools/make_blow5.py (uncompressed and zlib + svb-zd) through the library's own reader."""
+    """tools/make_blow5.py (every combination of record / signal compression) through the library's own reader."""
     import sigfish_amd as S
     src = os.path.join(ROOT, "tests", "golden", "data", "sp1_dna.blow5")
     want = list(S.Blow5File(src))
-    for flags in ([], ["--compress"]):
-        dst = str(tmp_path / ("c.blow5" if flags else "u.blow5"))
+    for k, flags in enumerate(([], ["--compress"], ["--record-press", "zlib"], ["--signal-press", "svb-zd"])):
+        dst = str(tmp_path / f"f{k}.blow5")
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), src, dst, "--copies", "2", *flags], check=True,
                        capture_output=True)
         got = list(S.Blow5File(dst))
         assert len(got) == 2 * len(want)
-        for k, (rid, meta, raw) in enumerate(got):
-            wid, wmeta, wraw = want[k % len(want)]
-            assert rid == f"{wid}_{k // len(want)}" and np.array_equal(raw, wraw)
+        for j, (rid, meta, raw) in enumerate(got):
+            wid, wmeta, wraw = want[j % len(want)]
+            assert rid == f"{wid}_{j // len(want)}" and np.array_equal(raw, wraw)
             assert all(meta[f] == wmeta[f] for f in ("digitisation", "offset", "range", "sampling_rate"))

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("dst")
     ap.add_argument("--copies", type=int, default=1000)
     ap.add_argument("--compress", action="store_true", help="zlib records + svb-zd signals (as real BLOW5 files)")
+    ap.add_argument("--record-press", choices=["none", "zlib"], default=None, help="record compression alone")
+    ap.add_argument("--signal-press", choices=["none", "svb-zd"], default=None, help="signal compression alone")
     a = ap.parse_args()
     f = S.Blow5File(a.src)
     reads = list(f)
@@ -49,19 +51,20 @@ def main():
     text = "".join(f"@{k}\t{v}\n" for k, v in attrs)
     text += "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
     text += "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
-    press = 1 if a.compress else 0
-    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([press]) + struct.pack("<I", 1) + bytes([press])
+    rec_zlib = (a.record_press == "zlib") if a.record_press else a.compress
+    sig_svb = (a.signal_press == "svb-zd") if a.signal_press else a.compress
+    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1 if rec_zlib else 0]) + struct.pack("<I", 1) + bytes([1 if sig_svb else 0])
     hdr += b"\0" * (64 - len(hdr)) + struct.pack("<I", len(text)) + text.encode()
     n = 0
     with open(a.dst, "wb") as out:
         out.write(hdr)
-        sig = [svb_zd(raw) if a.compress else raw.tobytes() for _, _, raw in reads]
+        sig = [svb_zd(raw) if sig_svb else raw.tobytes() for _, _, raw in reads]
         for c in range(a.copies):
             for (rid, meta, raw), body in zip(reads, sig):
                 name = f"{rid}_{c}".encode()
                 payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, meta["digitisation"], meta["offset"], meta["range"],
-                                                                          meta["sampling_rate"], len(body) if a.compress else len(raw)) + body
-                if a.compress:
+                                                                          meta["sampling_rate"], len(body) if sig_svb else len(raw)) + body
+                if rec_zlib:
                     payload = zlib.compress(payload, 6)
                 out.write(struct.pack("<Q", len(payload)) + payload)
                 n += 1
