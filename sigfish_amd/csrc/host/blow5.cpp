@@ -184,6 +184,14 @@ bool Blow5Reader::open(const std::string &path) {
     signal_press_ = (major > 0 || minor >= 2) ? head[14] : 0;
     uint32_t hsize;
     memcpy(&hsize, head + 64, 4);
+    {  // sizes read from the file are only trusted up to the size of the file
+        struct stat fsb;
+        file_size_ = (fstat(fileno(fp_), &fsb) == 0 && S_ISREG(fsb.st_mode)) ? static_cast<uint64_t>(fsb.st_size) : UINT64_MAX;
+    }
+    if (hsize > file_size_) {
+        err_ = path + ": malformed BLOW5 header (its size field exceeds the file)";
+        return false;
+    }
     std::string text(hsize, '\0');
     if (hsize && fread(&text[0], 1, hsize, fp_) != hsize) {
         err_ = path + ": truncated BLOW5 header";
@@ -253,6 +261,10 @@ int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
         err_ = "malformed BLOW5: missing end-of-file marker";
         return -1;
     }
+    if (size > file_size_ || (file_size_ == UINT64_MAX && size > (uint64_t(1) << 32))) {  // not a plausible record size
+        err_ = "malformed BLOW5: truncated record";
+        return -1;
+    }
     mem->resize(size);
     if (size && fread(mem->data(), 1, size, fp_) != size) {
         err_ = "malformed BLOW5: truncated record";
@@ -289,7 +301,7 @@ bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::
     }
     if (ok) {
         if (signal_press_ == 0) {
-            ok = static_cast<uint64_t>(end - p) >= len * 2;
+            ok = len <= static_cast<uint64_t>(end - p) / 2;  // (not len * 2: a corrupt length must not wrap around)
             if (ok) {
                 rec->raw.resize(len);
                 memcpy(rec->raw.data(), p, len * 2);

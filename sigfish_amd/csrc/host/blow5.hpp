@@ -50,6 +50,7 @@ class Blow5Reader {
     FILE *fp_ = nullptr;
     const uint8_t *map_ = nullptr;  // whole file, read-only mapping (nullptr: mmap unavailable, fall back to fread)
     size_t map_size_ = 0, map_pos_ = 0;
+    uint64_t file_size_ = UINT64_MAX;  // upper bound for every size field read from the file (UINT64_MAX: not a regular file)
     uint8_t record_press_ = 0, signal_press_ = 0;
     uint32_t n_groups_ = 1;
     std::map<std::string, std::string> attrs_;

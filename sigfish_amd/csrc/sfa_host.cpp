@@ -220,8 +220,14 @@ struct sfa_blow5 {
 
 sfa_blow5_t *sfa_blow5_open(const char *path) {
     sfa_blow5 *f = new sfa_blow5();
-    if (!path || !f->reader.open(path)) {
-        sfa_set_error_(path ? f->reader.error().c_str() : "null path");
+    bool ok = false;
+    try {
+        ok = path && f->reader.open(path);
+        if (!ok) sfa_set_error_(path ? f->reader.error().c_str() : "null path");
+    } catch (const std::exception &e) {  // e.g. bad_alloc on a corrupt size field: no exception crosses the C boundary
+        sfa_set_error_((std::string("malformed BLOW5: ") + e.what()).c_str());
+    }
+    if (!ok) {
         delete f;
         return nullptr;
     }
@@ -232,8 +238,14 @@ const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key) { return (f && key) 
 
 int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const int16_t **raw, int64_t *n_raw) {
     if (!f) return SFA_EINVAL;
-    const int rc = f->reader.next(&f->rec);
-    if (rc < 0) sfa_set_error_(f->reader.error().c_str());
+    int rc;
+    try {
+        rc = f->reader.next(&f->rec);
+        if (rc < 0) sfa_set_error_(f->reader.error().c_str());
+    } catch (const std::exception &e) {
+        sfa_set_error_((std::string("malformed BLOW5: ") + e.what()).c_str());
+        rc = -1;
+    }
     if (rc <= 0) return rc;
     if (read_id) *read_id = f->rec.read_id.c_str();
     if (meta) {

@@ -92,3 +92,28 @@ def test_sam_rows_from_reference_alignments(name):
         got.append(S.sam_row(r, rid, ref.names[int(r["rid"])], ev, qs, qe, arr, int(ref.st_offset[int(r["rid"])]), c["flag"]))
         vi += 1
     assert got == want
+
+
+def test_blow5_reader_rejects_corrupt_files(tmp_path):
+    """Flipped bytes, truncation, garbage size fields: an error (or, where the damage hits nothing that is checked, a
+    normal read), never a crash or an exception across the C boundary."""
+    src = open(os.path.join(GOLD, "data", "sp1_dna.blow5"), "rb").read()
+    rng = np.random.default_rng(5)
+    path = str(tmp_path / "fz.blow5")
+    rejected = 0
+    for it in range(300):
+        b = bytearray(src)
+        if it % 3 == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif it % 3 == 1:
+            b = b[:int(rng.integers(0, len(b)))]
+        else:
+            p = int(rng.integers(64, len(b) - 8))
+            b[p:p + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()
+        open(path, "wb").write(b)
+        try:
+            sum(1 for _ in S.Blow5File(path))
+        except Exception:
+            rejected += 1
+    assert rejected > 250
