@@ -341,6 +341,21 @@ def test_context_lifecycle_does_not_leak():
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
 
 
+def test_non_finite_queries_do_not_hang():
+    """NaN / inf query values are outside the contract (the reference is undefined there); the call must still return."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=16, seed=2)
+    q = q.copy()
+    q[5] = np.nan
+    q[int(q_off[3]) + 7] = np.inf
+    q[int(q_off[6]):int(q_off[7])] = np.nan
+    q[int(q_off[9]):int(q_off[10])] = 0.0   # a constant query (what a zero-variance read would give before dividing)
+    for mode in ("two_pass", "single_pass", "wide4_dense"):
+        with _aligner(ref, flag, mode) as al:
+            rows = al.align_db(q, q_off)
+        clean = [i for i in range(16) if i not in (0, 3, 6)]
+        assert (rows["valid"] == 1).all() and (rows["rid"][clean] == 0).all()
+
+
 def test_options_are_validated():
     ref = _small_ref(np.random.default_rng(0), [50], False)
     with S.Aligner(ref, 0) as al:
