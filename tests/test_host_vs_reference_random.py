@@ -1,0 +1,72 @@
+"""The host pre-DP stages (sigfish_amd/csrc/host/events.cpp: event detection, adaptor / poly-A query start, query window,
+z-normalisation) against the COMPILED REFERENCE on hundreds of synthetic step signals -- the fixtures alone are 13 reads.
+Runs where oracle/_ref exists (the build container); the device-side stages are in turn checked against these host stages
+(tests/test_raw_gpu.py, tools/fuzz_raw_gpu.py)."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import sigfish_amd as S
+from oracle import oracle as O
+from tests.util import GOLD, write_blow5
+
+pytestmark = pytest.mark.skipif(not os.path.exists(O.REF_DRIVER), reason="oracle/_ref not built (no /root/reference)")
+
+
+def _signal(rng, n):
+    dwell = rng.integers(2, int(rng.integers(4, 40)), size=n // 2 + 2)
+    levels = rng.normal(rng.uniform(300, 700), rng.uniform(20, 120), size=len(dwell))
+    x = np.repeat(levels, dwell)[:n]
+    if len(x) < n:
+        x = np.concatenate([x, np.full(n - len(x), 500.0)])
+    x = x + rng.normal(0, rng.uniform(0.5, 15), size=n)
+    if rng.integers(0, 6) == 0:
+        x = np.round(x / 8) * 8
+    return np.clip(np.round(x), -2000, 4000).astype(np.int16)
+
+
+@pytest.mark.parametrize("case", [("dna", []), ("dna_q100_p10", ["-q", "100", "-p", "10"]), ("dna_end", ["--from-end"]),
+                                  ("rna", ["--rna"]), ("rna_pauto", ["--rna", "-p", "-1"]), ("rna_q500", ["--rna", "-q", "500"])])
+def test_random_signals(case, tmp_path):
+    name, args = case
+    rna = "--rna" in args
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    reads = []
+    for k in range(150):
+        # (very short reads are outside the reference's domain: it asserts in trim_raw_by_mad, src/events.c:246, below ~200
+        # samples, and a 358-sample read made it abort with heap corruption; a real read has thousands of samples)
+        n = int(rng.choice([1000, 1500, 2500, 4000, 9000, 20000], p=[.05, .1, .2, .3, .25, .1]) * rng.uniform(0.6, 1.4))
+        reads.append((f"read{k}", float(rng.choice([2048.0, 8192.0])), float(rng.integers(-20, 40)), float(rng.uniform(700, 1500)), 4000.0,
+                      _signal(rng, n)))
+    blow5 = str(tmp_path / "rnd.blow5")
+    write_blow5(blow5, reads, attrs=(("experiment_type", "rna" if rna else "genomic_dna"), ("sequencing_kit", "unknown")))
+    k = 5 if rna else 6
+    fasta = os.path.join(GOLD, "data", "rnasequin_sequences_2.4.fa" if rna else "nCoV-2019.reference.fasta")
+    dump = str(tmp_path / "dump.bin")
+    subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), "--dump", dump, *args, fasta, blow5],
+                   check=True, capture_output=True)
+    d = O.parse_dump(dump)
+    prefix = int(args[args.index("-p") + 1]) if "-p" in args else 50
+    query = int(args[args.index("-q") + 1]) if "-q" in args else 250
+    flag = (S.RNA if rna else 0) | (S.END if "--from-end" in args else 0)
+    assert len(d["reads"]) == len(reads)
+    checked = 0
+    for want, (rid, dig, off, rng_, rate, raw) in zip(d["reads"], reads):
+        meta = dict(digitisation=dig, offset=off, range=rng_)
+        ev = S.detect_events(raw, meta, rna)
+        if want["valid"]:  # a read the reference drops has its event count zeroed (et.n = 0, src/sigfish.c:470-476)
+            assert want["n_events"] == len(ev), rid
+        keep, a, b = (False, 0, 0)
+        if len(ev):
+            keep, a, b = S.select_query(ev, raw, meta, prefix, query, flag, 0)
+        assert keep == want["valid"], rid
+        if keep:
+            assert (a, b) == (want["qstart"], want["qend"]), rid
+            assert np.array_equal(ev["mean"][a:b].view(np.uint32), want["query"].view(np.uint32)), rid
+            assert int(ev["start"][a]) == want["ev_start_first"] and int(ev["start"][b - 1]) == want["ev_start_last"]
+            assert np.float32(ev["length"][b - 1]) == want["ev_len_last"]
+            checked += 1
+    assert checked > 100

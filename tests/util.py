@@ -44,3 +44,22 @@ def paf_lines_from_results(O, c, res, ref_names, ref_seq_lengths):
                                int(c["len_raw"][i]), int(ref_seq_lengths[int(r["rid"])])))
         vi += 1
     return "".join(lines)
+
+
+def write_blow5(path, reads, attrs=(("experiment_type", "genomic_dna"), ("sequencing_kit", "unknown"))):
+    """Minimal uncompressed BLOW5 writer for synthetic test inputs: reads = [(read_id, digitisation, offset, range,
+    sampling_rate, int16 samples)].  Layout as tools/make_blow5.py / sigfish_amd/csrc/host/blow5.hpp."""
+    import struct
+    text = "".join(f"@{k}\t{v}\n" for k, v in attrs)
+    text += "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
+    text += "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([0]) + struct.pack("<I", 1) + bytes([0])
+    hdr += b"\0" * (64 - len(hdr)) + struct.pack("<I", len(text)) + text.encode()
+    with open(path, "wb") as out:
+        out.write(hdr)
+        for rid, dig, off, rng_, rate, raw in reads:
+            name = rid.encode()
+            raw = np.ascontiguousarray(raw, np.int16)
+            payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, dig, off, rng_, rate, len(raw)) + raw.tobytes()
+            out.write(struct.pack("<Q", len(payload)) + payload)
+        out.write(b"5WOLB")
