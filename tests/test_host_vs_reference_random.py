@@ -70,3 +70,44 @@ def test_random_signals(case, tmp_path):
             assert np.float32(ev["length"][b - 1]) == want["ev_len_last"]
             checked += 1
     assert checked > 100
+
+
+@pytest.mark.parametrize("case", [("dna_sam", ["--sam"]), ("rna_sam", ["--rna", "--sam"]), ("rna_fullref_sam", ["--rna", "--full-ref", "--sam", "-q", "400"])])
+def test_random_signals_sam(case, tmp_path):
+    """The SAM writer's warp-path recovery (band between the winner's start and end columns instead of the reference's
+    full-matrix traceback) on random alignments: the reference's own rows in, its SAM text out, byte for byte."""
+    name, args = case
+    rna = "--rna" in args
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    reads = []
+    for k in range(80):
+        n = int(rng.choice([2500, 4000, 9000], p=[.3, .4, .3]) * rng.uniform(0.7, 1.4))
+        reads.append((f"read{k}", 8192.0, float(rng.integers(-20, 40)), float(rng.uniform(700, 1500)), 4000.0, _signal(rng, n)))
+    blow5 = str(tmp_path / "rnd.blow5")
+    write_blow5(blow5, reads, attrs=(("experiment_type", "rna" if rna else "genomic_dna"), ("sequencing_kit", "unknown")))
+    k = 5 if rna else 6
+    fasta = os.path.join(GOLD, "data", "rnasequin_sequences_2.4.fa" if rna else "nCoV-2019.reference.fasta")
+    dump = str(tmp_path / "dump.bin")
+    out = subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), "--dump", dump, *args, fasta, blow5],
+                         check=True, capture_output=True).stdout.decode()
+    want = [l + "\n" for l in out.split("\n") if l and not l.startswith("@")]
+    d = O.parse_dump(dump)
+    query = int(args[args.index("-q") + 1]) if "-q" in args else 250
+    flag = (S.RNA if rna else 0) | (S.REF if "--full-ref" in args else 0)
+    levels = np.fromfile(os.path.join(GOLD, "models", f"syn{k}.f32"), np.float32)
+    ref = S.RefModel.from_fasta(fasta, levels, k, flag, query)
+    got = []
+    for w, (rid, dig, off, rng_, rate, raw) in zip(d["reads"], reads):
+        if not w["valid"]:
+            continue
+        meta = dict(digitisation=dig, offset=off, range=rng_)
+        ev = S.detect_events(raw, meta, rna)
+        keep, a, b = S.select_query(ev, raw, meta, 50, query, flag, 0)
+        assert keep and (a, b) == (w["qstart"], w["qend"])
+        row = np.zeros(1, S.RESULT_DTYPE)[0]
+        for f in ("rid", "pos_st", "pos_end", "score", "score2", "strand", "mapq"):
+            row[f] = w[f]
+        row["valid"] = 1
+        arr = ref.forward[int(row["rid"])] if row["strand"] == ord("+") else ref.reverse[int(row["rid"])]
+        got.append(S.sam_row(row, rid, ref.names[int(row["rid"])], ev, a, b, arr, int(ref.st_offset[int(row["rid"])]), flag))
+    assert len(got) > 60 and got == want
