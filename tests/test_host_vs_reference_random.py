@@ -111,3 +111,38 @@ def test_random_signals_sam(case, tmp_path):
         arr = ref.forward[int(row["rid"])] if row["strand"] == ord("+") else ref.reverse[int(row["rid"])]
         got.append(S.sam_row(row, rid, ref.names[int(row["rid"])], ev, a, b, arr, int(ref.st_offset[int(row["rid"])]), flag))
     assert len(got) > 60 and got == want
+
+
+@pytest.mark.parametrize("case", [("dna", [], 6), ("dna_q100", ["-q", "100"], 6), ("rna", ["--rna"], 5), ("rna_q500", ["--rna", "-q", "500"], 5),
+                                  ("rna_full", ["--rna", "--full-ref"], 5)])
+def test_random_fasta_gen_ref(case, tmp_path):
+    """gen_ref (src/genref.c:86-241) on random contigs -- lengths around the RNA slice limits, very short contigs --
+    against sfa_gen_ref_record: lengths, offsets and every float of the forward / reverse arrays."""
+    name, args, k = case
+    rna = "--rna" in args
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    query = int(args[args.index("-q") + 1]) if "-q" in args else 250
+    fasta = str(tmp_path / "rnd.fa")
+    with open(fasta, "w") as f:
+        for c in range(12):
+            # (with --full-ref a one-k-mer contig makes the reference's aligner assert, src/sigfish.c:611: start at 40 there)
+            n = int(rng.choice([40 if "--full-ref" in args else k, k + 36, 40, query, query + k, int(query * 1.5) + k - 1, int(query * 1.5) + k, 2000, 7000]))
+            seq = "".join(rng.choice(list("ACGT"), size=n))
+            f.write(f">contig{c} some description\n")
+            for i in range(0, n, 61):
+                f.write(seq[i:i + 61] + "\n")
+    dump = str(tmp_path / "dump.bin")
+    blow5 = os.path.join(GOLD, "data", "sequin_rna.blow5" if rna else "sp1_dna.blow5")
+    subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), "--dump", dump, *args, fasta, blow5],
+                   check=True, capture_output=True)
+    want = O.parse_dump(dump)["ref"]
+    flag = (S.RNA if rna else 0) | (S.REF if "--full-ref" in args else 0)
+    levels = np.fromfile(os.path.join(GOLD, "models", f"syn{k}.f32"), np.float32)
+    got = S.RefModel.from_fasta(fasta, levels, k, flag, query)
+    assert list(got.names) == list(want.names)
+    assert np.array_equal(got.ref_lengths, want.ref_lengths) and np.array_equal(got.seq_lengths, want.seq_lengths)
+    assert np.array_equal(got.st_offset, want.st_offset)
+    for i in range(got.num_ref):
+        assert np.array_equal(got.forward[i].view(np.uint32), want.forward[i].view(np.uint32)), i
+        if not rna:
+            assert np.array_equal(got.reverse[i].view(np.uint32), want.reverse[i].view(np.uint32)), i
