@@ -42,7 +42,13 @@ def test_random_signals(case, tmp_path):
         reads.append((f"read{k}", float(rng.choice([2048.0, 8192.0])), float(rng.integers(-20, 40)), float(rng.uniform(700, 1500)), 4000.0,
                       _signal(rng, n)))
     blow5 = str(tmp_path / "rnd.blow5")
-    write_blow5(blow5, reads, attrs=(("experiment_type", "rna" if rna else "genomic_dna"), ("sequencing_kit", "unknown")))
+    # half of the cases as real files are written (zlib records, svb-zd signals): the reference reads them through slow5lib,
+    # our stages through the library's own reader -- same events means same decoded samples
+    compress = name in ("dna_q100_p10", "rna", "rna_q500")
+    write_blow5(blow5, reads, attrs=(("experiment_type", "rna" if rna else "genomic_dna"), ("sequencing_kit", "unknown")), compress=compress)
+    if compress:
+        back = list(S.Blow5File(blow5))
+        assert len(back) == len(reads) and all(np.array_equal(b[2], r[5]) and b[0] == r[0] for b, r in zip(back, reads))
     k = 5 if rna else 6
     fasta = os.path.join(GOLD, "data", "rnasequin_sequences_2.4.fa" if rna else "nCoV-2019.reference.fasta")
     dump = str(tmp_path / "dump.bin")

@@ -46,20 +46,40 @@ def paf_lines_from_results(O, c, res, ref_names, ref_seq_lengths):
     return "".join(lines)
 
 
-def write_blow5(path, reads, attrs=(("experiment_type", "genomic_dna"), ("sequencing_kit", "unknown"))):
-    """Minimal uncompressed BLOW5 writer for synthetic test inputs: reads = [(read_id, digitisation, offset, range,
-    sampling_rate, int16 samples)].  Layout as tools/make_blow5.py / sigfish_amd/csrc/host/blow5.hpp."""
+def _svb_zd(raw):
+    """int16 samples -> u32 n | StreamVByte keys | little-endian bytes of the zig-zag deltas (as tools/make_blow5.py)."""
     import struct
+    x = raw.astype(np.int32)
+    d = np.diff(x, prepend=np.int32(0))
+    z = ((d << 1) ^ (d >> 31)).astype(np.uint32)
+    nb = np.where(z < (1 << 8), 1, np.where(z < (1 << 16), 2, np.where(z < (1 << 24), 3, 4))).astype(np.uint8)
+    n = len(z)
+    codes = np.zeros((n + 3) // 4 * 4, np.uint8)
+    codes[:n] = nb - 1
+    keys = (codes[0::4] | (codes[1::4] << 2) | (codes[2::4] << 4) | (codes[3::4] << 6)).astype(np.uint8)
+    b = z.view(np.uint8).reshape(n, 4)
+    return struct.pack("<I", n) + keys.tobytes() + b[np.arange(4)[None, :] < nb[:, None]].tobytes()
+
+
+def write_blow5(path, reads, attrs=(("experiment_type", "genomic_dna"), ("sequencing_kit", "unknown")), compress=False):
+    """Minimal BLOW5 writer for synthetic test inputs: reads = [(read_id, digitisation, offset, range, sampling_rate,
+    int16 samples)]; compress: zlib records + svb-zd signals.  Layout as tools/make_blow5.py / host/blow5.hpp."""
+    import struct
+    import zlib
     text = "".join(f"@{k}\t{v}\n" for k, v in attrs)
     text += "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
     text += "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
-    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([0]) + struct.pack("<I", 1) + bytes([0])
+    press = 1 if compress else 0
+    hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([press]) + struct.pack("<I", 1) + bytes([press])
     hdr += b"\0" * (64 - len(hdr)) + struct.pack("<I", len(text)) + text.encode()
     with open(path, "wb") as out:
         out.write(hdr)
         for rid, dig, off, rng_, rate, raw in reads:
             name = rid.encode()
             raw = np.ascontiguousarray(raw, np.int16)
-            payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, dig, off, rng_, rate, len(raw)) + raw.tobytes()
+            body = _svb_zd(raw) if compress else raw.tobytes()
+            payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, dig, off, rng_, rate, len(body) if compress else len(raw)) + body
+            if compress:
+                payload = zlib.compress(payload, 6)
             out.write(struct.pack("<Q", len(payload)) + payload)
         out.write(b"5WOLB")
