@@ -52,8 +52,8 @@ def test_random_signals(case, tmp_path):
     k = 5 if rna else 6
     fasta = os.path.join(GOLD, "data", "rnasequin_sequences_2.4.fa" if rna else "nCoV-2019.reference.fasta")
     dump = str(tmp_path / "dump.bin")
-    subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), "--dump", dump, *args, fasta, blow5],
-                   check=True, capture_output=True)
+    paf = subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), "--dump", dump, *args, fasta, blow5],
+                         check=True, capture_output=True).stdout.decode()
     d = O.parse_dump(dump)
     prefix = int(args[args.index("-p") + 1]) if "-p" in args else 50
     query = int(args[args.index("-q") + 1]) if "-q" in args else 250
@@ -76,6 +76,21 @@ def test_random_signals(case, tmp_path):
             assert np.float32(ev["length"][b - 1]) == want["ev_len_last"]
             checked += 1
     assert checked > 100
+    # the alignment and the PAF text for the same reads: our CPU restatement of the alignment stage (the oracle the GPU
+    # tests compare against) on the host stages' queries, printed by sfa_paf_row, against what the reference printed
+    valid = [(w, r) for w, r in zip(d["reads"], reads) if w["valid"]]
+    q = np.concatenate([w["query"] for w, _ in valid])
+    q_off = np.concatenate([[0], np.cumsum([len(w["query"]) for w, _ in valid])]).astype(np.int64)
+    rows = O.align_batch(q, q_off, d["ref"], d["flag"], threads=8)
+    lines = []
+    for (w, (rid, dig, off, rng_, rate, raw)), r in zip(valid, rows):
+        for f in ("rid", "pos_st", "pos_end", "strand", "mapq"):
+            assert r[f] == w[f], (rid, f)
+        assert np.float32(r["score"]) == w["score"] and (np.float32(r["score2"]) == w["score2"] or (np.isinf(r["score2"]) and np.isinf(w["score2"])))
+        end_raw = int(np.float32(np.float32(w["ev_start_last"]) + w["ev_len_last"]))  # u64 + float in C: fp32 arithmetic
+        lines.append(S.paf_row(r, rid, d["ref"].names[int(r["rid"])], w["ev_start_first"], end_raw, (w["qend"] - 1) - w["qstart"], len(raw),
+                               int(d["ref"].seq_lengths[int(r["rid"])])))
+    assert "".join(lines) == paf
 
 
 @pytest.mark.parametrize("case", [("dna_sam", ["--sam"]), ("rna_sam", ["--rna", "--sam"]), ("rna_fullref_sam", ["--rna", "--full-ref", "--sam", "-q", "400"])])
