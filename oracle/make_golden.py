@@ -160,6 +160,41 @@ def eval_goldens():
     print("eval goldens:", len(pairs))
 
 
+def random_goldens():
+    """Synthetic step signals (compressed BLOW5, 40 reads each) through the reference's batch loop: more end-to-end
+    known answers for the command line than the 13 reads of the reference's own fixtures."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import write_blow5  # noqa: E402
+    rd = os.path.join(GOLD, "random")
+    os.makedirs(rd, exist_ok=True)
+
+    def signal(rng, n):
+        dwell = rng.integers(2, int(rng.integers(4, 40)), size=n // 2 + 2)
+        levels = rng.normal(rng.uniform(300, 700), rng.uniform(20, 120), size=len(dwell))
+        x = np.repeat(levels, dwell)[:n]
+        if len(x) < n:
+            x = np.concatenate([x, np.full(n - len(x), 500.0)])
+        x = x + rng.normal(0, rng.uniform(0.5, 15), size=n)
+        return np.clip(np.round(x), -2000, 4000).astype(np.int16)
+
+    for kind, k, fasta, cases in (("dna", 6, "nCoV-2019.reference.fasta", [("rnd_dna", []), ("rnd_dna_sam", ["--sam"]), ("rnd_dna_end_q100", ["--from-end", "-q", "100"])]),
+                                  ("rna", 5, "rnasequin_sequences_2.4.fa", [("rnd_rna", ["--rna"]), ("rnd_rna_pauto", ["--rna", "-p", "-1"]),
+                                                                             ("rnd_rna_full_std", ["--rna", "--full-ref", "--dtw-std"])])):
+        rng = np.random.default_rng(20241004 + k)
+        reads = [(f"{kind}{i:03d}", float(rng.choice([2048.0, 8192.0])), float(rng.integers(-20, 40)), float(rng.uniform(700, 1500)), 4000.0,
+                  signal(rng, int(rng.integers(1500, 5000)))) for i in range(40)]
+        blow5 = os.path.join(rd, f"rnd_{kind}.blow5")
+        write_blow5(blow5, reads, attrs=(("experiment_type", "rna" if kind == "rna" else "genomic_dna"), ("sequencing_kit", "unknown")), compress=True)
+        for name, args in cases:
+            out = subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), *args,
+                                  os.path.join(GOLD, "data", fasta), blow5], check=True, capture_output=True).stdout
+            with open(os.path.join(rd, name + ".out"), "wb") as f:
+                f.write(out)
+            with open(os.path.join(rd, name + ".args"), "w") as f:
+                f.write("\n".join([str(k), fasta, os.path.basename(blow5)] + args))
+    print("random goldens written")
+
+
 def main():
     O.build()
     assert os.path.exists(O.REF_DRIVER), "oracle/_ref missing (needs /root/reference)"
@@ -176,6 +211,7 @@ def main():
         run_case(*c)
     kernel_vectors()
     eval_goldens()
+    random_goldens()
 
 
 if __name__ == "__main__":

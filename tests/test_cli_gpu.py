@@ -1,6 +1,7 @@
 """End to end: the `sigfish-amd dtw` command line (own BLOW5/FASTA/model readers, event detection, query window,
 GPU alignment through the C-ABI, PAF writer) must print exactly what the compiled reference printed for the
 same files and flags (tests/golden/cases/*.out) -- "PAF identical to CPU on test/test.sh"."""
+import glob
 import itertools
 import os
 import subprocess
@@ -87,6 +88,23 @@ def test_cli_empty_file_and_odd_batch_settings(models, tmp_path):
     for extra in (["-K", "100000"], ["-B", "1K"]):   # batch larger than the file; byte cap of one record
         r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "0", *extra, c["fasta"], c["blow5"]], capture_output=True, timeout=120)
         assert r.returncode == 0 and r.stdout.decode() == c["out_text"], r.stderr.decode()
+
+
+RANDOM_CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "random", "*.args")))
+
+
+@pytest.mark.parametrize("name", RANDOM_CASES)
+@pytest.mark.parametrize("extra", [[], ["-K", "7"], ["--host-events"]])
+def test_cli_random_signal_goldens(name, extra, models):
+    """Synthetic step signals in compressed BLOW5 files (40 reads each) whose PAF / SAM text the compiled reference
+    printed (tests/golden/random, oracle/make_golden.py): the command line must print the same, through device-side and
+    host-side event detection, in one batch and in several."""
+    k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
+    cmd = [BIN, "dtw", "--kmer-model", models[int(k)], "--verbose", "0", *args, *extra, os.path.join(GOLD, "data", fasta),
+           os.path.join(GOLD, "random", blow5)]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == open(os.path.join(GOLD, "random", name + ".out")).read()
 
 
 def test_cli_errors_like_reference(models):
