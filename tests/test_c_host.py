@@ -60,3 +60,25 @@ def test_c_host_matches_oracle(tmp_path, oracle, rna):
     assert np.array_equal(got["valid"], want["valid"])
     v = want["valid"] == 1
     assert got[v].tobytes() == want[v].tobytes()
+
+
+def test_host_units_under_sanitizers(tmp_path):
+    """ASan + UBSan over the host-side C++ (reader, inflate, StreamVByte, events, query selection, planner): CPU build
+    only -- the GPU pool runs no sanitizers."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "sigfish_amd", "csrc")
+    exe = str(tmp_path / "host_asan")
+    units = [os.path.join(csrc, u) for u in ("sfa_host.cpp", "host/blow5.cpp", "host/inflate.cpp", "host/events.cpp", "host/refio.cpp", "host/sam.cpp")]
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                            "-I", csrc, "-o", exe, os.path.join(ROOT, "tests", "c", "host_asan.cpp"), *units, "-lz", "-lpthread"],
+                           capture_output=True, timeout=600)
+    if build.returncode != 0 and b"sanitize" in build.stderr:
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert build.returncode == 0, build.stderr.decode()[-2000:]
+    data = os.path.join(ROOT, "tests", "golden")
+    run = subprocess.run([exe, str(tmp_path), os.path.join(data, "data", "sp1_dna.blow5"), os.path.join(data, "data", "sequin_rna.blow5"),
+                          os.path.join(data, "random", "rnd_dna.blow5")], capture_output=True, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr).decode()[-3000:]
+    assert b"ERROR: AddressSanitizer" not in run.stderr and b"runtime error" not in run.stderr, run.stderr.decode()[-3000:]
