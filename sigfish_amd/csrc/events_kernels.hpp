@@ -322,28 +322,26 @@ __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
             const int j = base + jj - k;  // the sample this lane looks at
             const float cur = k ? (jj ? c[jj ? jj - 1 : 0] : carry) : c[jj];
             int peak = -1, mask_to = -1;  // what this lane's detector did: a peak to emit, a mask for the long detector
-            if (j >= 0 && j < n && p.masked_to < j) {
-                if (p.peak_pos == -1) {
-                    if (cur < p.peak_value) {
-                        p.peak_value = cur;
-                    } else if (cur - p.peak_value > a.peak_height) {
-                        p.peak_value = cur;
-                        p.peak_pos = j;
-                    }
-                } else {
-                    if (cur > p.peak_value) {
-                        p.peak_value = cur;
-                        p.peak_pos = j;
-                    }
-                    if (k == 0 && p.peak_value > p.threshold) mask_to = p.peak_pos + p.window;  // the short detector masks the long one
-                    if (p.peak_value - cur > a.peak_height && p.peak_value > p.threshold) p.valid = true;
-                    if (p.valid && (j - p.peak_pos) > p.window / 2) {
-                        if (p.peak_pos > 0 && p.peak_pos < n) peak = p.peak_pos;  // create_events() skips peaks at 0 / >= n
-                        p.peak_pos = -1;
-                        p.peak_value = cur;
-                        p.valid = false;
-                    }
-                }
+            // the reference's nested ifs (src/events.c:375-446) as selects: with one detector per lane this is 18 % faster
+            // than branches (the two-detectors-per-lane version was the other way round)
+            {
+                const bool active = j >= 0 && j < n && p.masked_to < j;
+                const bool searching = p.peak_pos == -1;
+                const bool lower = cur < p.peak_value;
+                const bool rise = !lower && (cur - p.peak_value > a.peak_height);
+                const bool higher = cur > p.peak_value;
+                const float b_value = higher ? cur : p.peak_value;
+                const int b_pos = higher ? j : p.peak_pos;
+                const bool tracking = active && !searching;
+                mask_to = (tracking && k == 0 && b_value > p.threshold) ? b_pos + p.window : -1;
+                const bool v2 = p.valid || (b_value - cur > a.peak_height && b_value > p.threshold);
+                const bool fire = tracking && v2 && (j - b_pos) > p.window / 2;
+                peak = (fire && b_pos > 0 && b_pos < n) ? b_pos : -1;
+                const float s_value = (lower || rise) ? cur : p.peak_value;
+                const int s_pos = rise ? j : -1;
+                p.peak_value = active ? (searching ? s_value : (fire ? cur : b_value)) : p.peak_value;
+                p.peak_pos = active ? (searching ? s_pos : (fire ? -1 : b_pos)) : p.peak_pos;
+                p.valid = tracking ? (fire ? false : v2) : p.valid;
             }
             const int other_peak = pair_swap(peak), other_mask = pair_swap(mask_to);
             const int peak_long = k ? peak : other_peak, peak_short = k ? other_peak : peak;
