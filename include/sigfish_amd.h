@@ -141,7 +141,9 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
  * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 5), "min_slice_reads" (a batch whose
  * checkpoints would not fit the budget at the shortest interval is cut into slices of at least this many reads, run
  * back to back; default 65536), "ev_parallel_prefix" (sfa_align_raw: 1 = wave-per-read prefix sums for every read
- * whose sums are provably exact in any order, the sequential kernel for the rest; 0 = sequential for all). */
+ * whose sums are provably exact in any order, the sequential kernel for the rest; 0 = sequential for all),
+ * "ev_parallel_peaks" (the same for the peak picker: 1 = chunk-parallel walk accepted where it is certified to equal the
+ * sequential one). */
 int sfa_set_option(sfa_ctx_t *ctx, const char *key, int64_t value);
 
 /* Plan a batch without running it: how reads would be grouped.  slot_of_read[n_reads] (may be NULL) receives

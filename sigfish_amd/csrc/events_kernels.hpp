@@ -35,6 +35,8 @@ struct EvArgs {
     int32_t w1, w2;         // detector windows (3,6 DNA / 7,14 RNA)
     int32_t *seq_flag;      // [n] written by ev_prefix_par_kernel: 1 = this read needs the sequential prefix sums
     int32_t use_flags;      // 0: ev_prefix_kernel sums every read; 1: only the flagged ones
+    int32_t *peak_flag;     // [n] written by ev_peaks_spec_kernel: 1 = this read needs the sequential peak picker
+    int32_t use_peak_flags; // 0: ev_peaks_kernel walks every read; 1: only the flagged ones
     float thr1, thr2, peak_height;
 };
 
@@ -266,11 +268,11 @@ __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
     const int lane = threadIdx.x;
     const int r = lane >> 1, k = lane & 1;  // read of the block, detector
     const int i = blockIdx.x * 32 + r;
-    const bool live = i < a.n_reads;
+    const bool live = i < a.n_reads && !(a.use_peak_flags && a.peak_flag[i] == 0);
     if (lane < 32) {
         const int ii = blockIdx.x * 32 + lane;
-        const bool lv = ii < a.n_reads;
-        const int64_t bb = a.raw_off[lv ? ii : a.n_reads - 1];
+        const bool lv = ii < a.n_reads && !(a.use_peak_flags && a.peak_flag[ii] == 0);  // done by ev_peaks_spec_kernel
+        const int64_t bb = a.raw_off[ii < a.n_reads ? ii : a.n_reads - 1];
         lds_b[lane] = bb;
         lds_n[lane] = lv ? static_cast<int32_t>(a.raw_off[ii + 1] - bb) : 0;
     }
@@ -373,6 +375,179 @@ __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
         nev = 0;
     }
     a.n_events[i] = nev;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The peak picker with the 64 lanes of a wave on ONE read: lane l walks samples [l*C, (l+1)*C) from a GUESSED state (the
+// initial one), and the result is accepted only where it is provably the sequential one:
+//   * whenever the short detector fires at sample j for a peak at pk, the complete state after that sample is a
+//     function of (j, pk, t1[j]) alone: the short detector restarts from t1[j], and the long one was masked and reset
+//     by the short one in that very sample (a firing short detector stands above its threshold: src/events.c:411-425);
+//   * so lane l, once its own state is known to be true, keeps walking into lane l+1's samples until it fires the short
+//     detector at a (j, pk) that lane l+1's speculative walk fired too: from there on lane l+1's walk IS the sequential
+//     one (induction from lane 0, whose start is the true start).  What lane l+1 emitted before that point is replaced
+//     by what lane l emitted while catching up.
+// A read where some lane finds no such point inside the next chunk (or overflows its list) is flagged and left to the
+// sequential kernel; so are very short and very long reads.
+constexpr int kSpecCap = 96;        // emissions a lane can hold (own chunk + catching up)
+constexpr int kSpecMinChunk = 24;   // samples per lane below which speculation is not worth it
+
+struct Det2 {
+    PeakDet32 d[2];
+};
+
+// one sample through both detectors, in the reference's order (short, then long); a fired peak is returned if
+// create_events() would keep it (0 < pk < n), else -1.  stop_after_short: leave the long detector alone.
+__device__ __forceinline__ void det2_step(Det2 &D, const EvArgs &a, int n, int j, float c0, float c1, int &pk_short, int &pk_long,
+                                          bool &short_fired, int &short_pk) {
+    pk_short = -1;
+    pk_long = -1;
+    short_fired = false;
+    short_pk = -1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        PeakDet32 &p = D.d[k];
+        if (p.masked_to >= j) continue;
+        const float cur = k ? c1 : c0;
+        if (p.peak_pos == -1) {
+            if (cur < p.peak_value) {
+                p.peak_value = cur;
+            } else if (cur - p.peak_value > a.peak_height) {
+                p.peak_value = cur;
+                p.peak_pos = j;
+            }
+        } else {
+            if (cur > p.peak_value) {
+                p.peak_value = cur;
+                p.peak_pos = j;
+            }
+            if (k == 0 && p.peak_value > p.threshold) {  // the short detector masks the long one
+                D.d[1].masked_to = p.peak_pos + p.window;
+                D.d[1].peak_pos = -1;
+                D.d[1].peak_value = 3.402823466e+38f;
+                D.d[1].valid = false;
+            }
+            if (p.peak_value - cur > a.peak_height && p.peak_value > p.threshold) p.valid = true;
+            if (p.valid && (j - p.peak_pos) > p.window / 2) {
+                const int pk = p.peak_pos;
+                if (k == 0) {
+                    short_fired = true;
+                    short_pk = pk;
+                }
+                if (pk > 0 && pk < n) (k ? pk_long : pk_short) = pk;
+                p.peak_pos = -1;
+                p.peak_value = cur;
+                p.valid = false;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) ev_peaks_spec_kernel(const EvArgs a) {
+    // per lane: the kept peaks in emission order, and for every firing of the short detector its sample, its peak and the
+    // number of list entries before it
+    __shared__ int e_pk[64][kSpecCap];
+    __shared__ int f_j[64][kSpecCap / 2], f_pk[64][kSpecCap / 2], f_at[64][kSpecCap / 2];
+    __shared__ int n_own[64], n_fire[64], sync_from[64];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int64_t b = a.raw_off[i];
+    const int n = static_cast<int>(a.raw_off[i + 1] - b);
+    const int C = (n + 63) / 64;
+    if (C < kSpecMinChunk || C > 3 * kSpecCap) {  // too short to split, or too long for the lists: sequential kernel
+        if (lane == 0) a.peak_flag[i] = 1;
+        return;
+    }
+    const float *t1 = a.t1 + b, *t2 = a.t2 + b;
+    const int c0 = min(n, lane * C), c1 = min(n, c0 + C);
+    Det2 D;
+    D.d[0] = PeakDet32{a.thr1, a.w1, 0, -1, 3.402823466e+38f, false};
+    D.d[1] = PeakDet32{a.thr2, a.w2, 0, -1, 3.402823466e+38f, false};
+    bool fail = false;
+    int cnt = 0, fires = 0;
+    // ---- phase 1: own chunk from the guessed state ----
+    for (int j = c0; j < c1; ++j) {
+        int ps, pl, spk;
+        bool sf;
+        det2_step(D, a, n, j, t1[j], t2[j], ps, pl, sf, spk);
+        if (sf) {
+            if (fires < kSpecCap / 2) {
+                f_j[lane][fires] = j;
+                f_pk[lane][fires] = spk;
+                f_at[lane][fires] = cnt;
+                ++fires;
+            } else {
+                fail = true;
+            }
+        }
+        if (ps >= 0) {
+            if (cnt < kSpecCap) e_pk[lane][cnt] = ps;
+            ++cnt;
+        }
+        if (pl >= 0) {
+            if (cnt < kSpecCap) e_pk[lane][cnt] = pl;
+            ++cnt;
+        }
+    }
+    fail = fail || cnt > kSpecCap;
+    n_own[lane] = cnt;
+    n_fire[lane] = fires;
+    sync_from[lane] = 0;  // lane 0 starts from the true state: everything it emitted counts
+    __syncthreads();
+    // ---- phase 2: catch up into the next lane's chunk until the two walks agree on a firing of the short detector ----
+    const bool has_next = lane < 63 && c1 < n;  // (a chunk that starts at n is empty)
+    if (has_next && !fail) {
+        const int nl = lane + 1;
+        const int nf = n_fire[nl];
+        const int end = min(n, c1 + C);
+        int m = 0;  // next candidate firing of lane l+1
+        bool synced = false;
+        for (int j = c1; j < end && !synced; ++j) {
+            int ps, pl, spk;
+            bool sf;
+            det2_step(D, a, n, j, t1[j], t2[j], ps, pl, sf, spk);
+            while (m < nf && f_j[nl][m] < j) ++m;
+            if (sf && m < nf && f_j[nl][m] == j && f_pk[nl][m] == spk) {
+                sync_from[nl] = f_at[nl][m];  // lane l+1's list counts from the entry of this firing on (or the next one kept)
+                synced = true;
+                break;                        // the long detector's turn at this sample belongs to lane l+1's walk
+            }
+            if (ps >= 0) {
+                if (cnt < kSpecCap) e_pk[lane][cnt] = ps;
+                ++cnt;
+            }
+            if (pl >= 0) {
+                if (cnt < kSpecCap) e_pk[lane][cnt] = pl;
+                ++cnt;
+            }
+        }
+        fail = !synced || cnt > kSpecCap;
+    }
+    if (__any(fail)) {
+        if (lane == 0) a.peak_flag[i] = 1;
+        return;
+    }
+    __syncthreads();
+    // ---- phase 3: lane l contributes its own entries from its agreed point on, then what it emitted while catching up ----
+    const int from = sync_from[lane], own = n_own[lane];
+    const int mine = (c0 < n ? own - from : 0) + (cnt - own);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    const int total = __shfl(incl, 63);
+    const int64_t eo = a.ev_off[i];
+    int32_t *evs = a.ev_start + eo;  // capacity n + 2 > total + 1
+    int w = 1 + incl - mine;         // event e starts at the (e-1)-th peak, event 0 at sample 0
+    if (c0 < n)
+        for (int k = from; k < own; ++k) evs[w++] = e_pk[lane][k];
+    for (int k = own; k < cnt; ++k) evs[w++] = e_pk[lane][k];
+    if (lane == 0) {
+        evs[0] = 0;
+        a.n_events[i] = total ? total + 1 : 0;  // the last event runs to the end of the signal; no peak at all -> no events
+        a.peak_flag[i] = 0;
+    }
 }
 
 // create_event(), src/events.c:461-477: event e of a read spans [start_e, start_{e+1}) (the last one ends with the

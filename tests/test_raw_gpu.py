@@ -134,3 +134,32 @@ def test_query_window_events_come_back_for_sam():
         got = qev[i][:b - a]
         for f in ("start", "length", "mean", "stdv"):
             assert np.array_equal(got[f], ev[f][a:b]), (i, f)
+
+
+def test_parallel_peak_picker_and_its_fallback():
+    """The chunk-parallel peak picker is accepted only where every lane's walk re-joins the sequential one; reads it
+    declines (here: too short or too long to split) go through the sequential kernel.  Either way, and with the option
+    off, the same events, windows and rows."""
+    c = load_case("dna_default")
+    ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
+    ids, raw, off, scal = _load_raw(c["blow5"])
+    raws, scs = [], []
+    for k in range(70):
+        i = k % 5
+        r = raw[off[i]:off[i + 1]]
+        if k % 4 == 1:
+            r = r[:1200]                      # 18 samples per lane: below the speculation threshold
+        elif k % 4 == 2:
+            r = np.tile(r, 5)[:20000]         # more than 288 samples per lane: above it
+        raws.append(r)
+        scs.append(scal[i])
+    off2 = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int64)
+    raw2 = np.concatenate(raws)
+    with S.Aligner(ref, 0) as al:
+        rows_par, info_par, ev_par = al.align_raw(raw2, off2, np.array(scs), 50, 250, return_events=True)
+        al.set_option("ev_parallel_peaks", 0)
+        rows_seq, info_seq, ev_seq = al.align_raw(raw2, off2, np.array(scs), 50, 250, return_events=True)
+    assert rows_par.tobytes() == rows_seq.tobytes() and info_par.tobytes() == info_seq.tobytes() and ev_par.tobytes() == ev_seq.tobytes()
+    for k in (0, 1, 2, 3, 64, 69):
+        meta = dict(digitisation=scs[k][0], offset=scs[k][1], range=scs[k][2])
+        assert info_par["n_events"][k] == len(S.detect_events(raws[k], meta, False))

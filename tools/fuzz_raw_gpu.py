@@ -54,6 +54,8 @@ def main():
         with S.Aligner(ref, flag) as al:
             if rng.integers(0, 3) == 0:
                 al.set_option("ev_parallel_prefix", 0)
+            if rng.integers(0, 3) == 0:
+                al.set_option("ev_parallel_peaks", 0)
             rows, info, qev = al.align_raw(cat, off, np.array(scs), prefix, query, return_events=True)
             tabs, qs, qe = [], [], []
             for k, r in enumerate(raws):
