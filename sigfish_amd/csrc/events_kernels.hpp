@@ -582,23 +582,36 @@ struct QueryArgs {
     int32_t n_reads;
 };
 
+// One wave per read: the window's means are staged in LDS with coalesced loads, lane 0 accumulates the two sequential
+// fp32 sums out of LDS (their order is what makes the result the reference's), all lanes normalise and store.
+constexpr int kQueryStage = 2048;  // = SFA_MAX_QUERY events
+
 __global__ void __launch_bounds__(64) ev_query_kernel(const QueryArgs a) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= a.n_reads) return;
-    const int64_t o = a.q_off[i], len = a.q_off[i + 1] - o;
+    __shared__ float m[kQueryStage];
+    __shared__ float stat[2];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int64_t o = a.q_off[i];
+    const int len = static_cast<int>(a.q_off[i + 1] - o);
     if (len <= 0) return;
-    const float *m = a.ev_mean + a.ev_off[i] + a.qstart[i];
-    const float cnt = static_cast<float>(len);
-    float mean = 0.0f, var = 0.0f;
-    for (int64_t j = 0; j < len; ++j) mean += m[j];
-    mean /= cnt;
-    for (int64_t j = 0; j < len; ++j) {
-        const float dv = m[j] - mean;
-        var += dv * dv;
+    const float *src = a.ev_mean + a.ev_off[i] + a.qstart[i];
+    for (int j = lane; j < len; j += 64) m[j] = src[j];
+    __syncthreads();
+    if (lane == 0) {
+        const float cnt = static_cast<float>(len);
+        float mean = 0.0f, var = 0.0f;
+        for (int j = 0; j < len; ++j) mean += m[j];
+        mean /= cnt;
+        for (int j = 0; j < len; ++j) {
+            const float dv = m[j] - mean;
+            var += dv * dv;
+        }
+        var /= cnt;
+        stat[0] = mean;
+        stat[1] = static_cast<float>(sqrt(static_cast<double>(var)));
     }
-    var /= cnt;
-    const float sd = static_cast<float>(sqrt(static_cast<double>(var)));
-    for (int64_t j = 0; j < len; ++j) a.queries[o + j] = (m[j] - mean) / sd;
+    __syncthreads();
+    const float mean = stat[0], sd = stat[1];
+    for (int j = lane; j < len; j += 64) a.queries[o + j] = (m[j] - mean) / sd;
 }
 
 // The query window's event table in the layout of event_t / sfa_event_t (src/sigfish.h:57-64), means z-normalised, for

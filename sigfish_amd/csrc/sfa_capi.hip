@@ -755,7 +755,8 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
     HIP_TRY(hipMemcpyAsync(c->e_qoff.p, q_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
     sfa::QueryArgs qa{c->e_evmean.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(), c->e_qoff.as<int64_t>(),
                       c->d_queries.as<float>(), n};
-    hipLaunchKernelGGL(sfa::ev_query_kernel, lane_grid, lane_block, 0, st, qa);
+    static_assert(sfa::kQueryStage >= SFA_MAX_QUERY, "query staging");
+    hipLaunchKernelGGL(sfa::ev_query_kernel, dim3(n), dim3(64), 0, st, qa);  // one wave per read
     sfa::BoundsArgs ba{c->e_evstart.as<int32_t>(), c->e_evlen.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(),
                        c->e_qoff.as<int64_t>(), c->e_b0.as<int32_t>(), c->e_b1.as<int32_t>(), c->e_b2.as<float>(), n};
     hipLaunchKernelGGL(sfa::ev_bounds_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ba);
