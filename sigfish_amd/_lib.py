@@ -25,7 +25,7 @@ class SfaProfile(C.Structure):
     _fields_ = [("fill_ms", C.c_double), ("trace_ms", C.c_double), ("finalize_ms", C.c_double),
                 ("total_ms", C.c_double), ("cells", C.c_int64), ("fill_launches", C.c_int64),
                 ("ckpt_interval", C.c_int64), ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64),
-                ("n_chunks", C.c_int64)]
+                ("n_chunks", C.c_int64), ("n_segments", C.c_int64), ("segment_reruns", C.c_int64)]
 
 
 class SfaPlanInfo(C.Structure):

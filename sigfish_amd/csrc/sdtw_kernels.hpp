@@ -99,6 +99,13 @@ struct DpArgs {
     int32_t ck_shift;      // checkpoint interval T = 1 << ck_shift steps; 0 = no checkpoints
     int32_t trace_margin;  // pass 2 starts from the last checkpoint at least this many steps before the winner
     int32_t n_reads_total; // reads in the batch (trace output: start columns [n], end columns [n])
+    // column segments (small batches, 64-lane shapes, cost-only sDTW): a chunk is (job, segment), see sweep_segment()
+    int32_t n_seg;         // segments per job (1 = off)
+    int32_t warm_windows;  // query-length windows a segment starts before its own first window
+    int32_t n_jobs;
+    int32_t verify_planes; // floats per lane in a hand-over snapshot (max R + 1)
+    float *verify;         // [quad][job][segment][in,out][verify_planes][64]
+    int32_t *seg_fail;     // [quad] set when a hand-over does not match
 };
 
 // Neighbour exchange.  Lane g needs the bottom cost lane g-1 produced in the previous step.  On gfx950 a
@@ -441,6 +448,188 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Column segments: the latency of a small batch is one wave walking a whole strand (30 k dependent steps).  A segment
+// wave starts `warm_windows` windows before its own first window FROM THE JOB'S INITIAL STATE (all costs +inf, free start
+// in row 0) -- a guess: the true state there depends on everything before.  But accumulated costs of paths that began
+// more than a few query lengths back never survive the min, so after the warm-up the anti-diagonal state is normally
+// the true one, and that is CHECKED: the wave stores its state where its own windows begin, the wave of the previous
+// segment stores its state where it ends (the same step of the same sweep), and sdtw_verify_kernel compares the two
+// bit for bit.  Equal state => everything the segment computed from there on is what the single sweep computes (every
+// cell is a pure function of its neighbours).  Any mismatch flags the quad and the host re-runs the batch unsegmented.
+// Windows, blocks of four steps and checkpoints fall on the same steps as in the single sweep because segments start
+// on window boundaries; checkpoints and candidates of the warm-up are simply not stored.
+__device__ __forceinline__ int64_t verify_slot(const DpArgs &a, int quad, int job, int seg, int which) {
+    return ((((static_cast<int64_t>(quad) * a.n_jobs + job) * a.n_seg + seg) * 2 + which) * a.verify_planes) * 64;
+}
+
+template <int R, int RQ>
+__device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
+                                              const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<false> &top,
+                                              const int job, float *ckp, const int T, const int col0, const int col_real, const int col_end,
+                                              float *vin, float *vout) {
+    typename Vec<float, R>::type cv;
+    typename Vec<int, R>::type sv;  // unused (cost-only), kept for dp_step's signature
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        cv[r] = INFINITY;
+        sv[r] = 0;
+    }
+    float dprev = INFINITY;
+    int sdprev = 0;
+    xc.template set_boundary<false>(lane0, 0.0f);
+
+    const int e_pro = lq - t_begin;  // prologue length of the single sweep: the last row is at column e - e_pro
+    int e = col0;                    // global step index: the sweep is entered where the single sweep is after col0 columns
+    const int e_real = col_real + e_pro;
+    int ck_next = T ? T * (e / T + 1) : 0x7fffffff;
+    if (T) ckp += static_cast<int64_t>(e / T) * (ck_planes<R>() * 64);
+    const int ck_last = T ? ((rlen > 4 ? rlen - 4 : 0) >> a.ck_shift) << a.ck_shift : 0;
+    auto maybe_checkpoint = [&]() {
+        if (T) {
+            if (e >= ck_next && ck_next <= ck_last) {
+                if (e >= e_real) {  // (before that the state is the guess: the previous segment owns these records)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
+                    ckp[R * 64] = dprev;
+                    ckp[(R + 1) * 64] = __int_as_float(e);
+                }
+                ckp += ck_planes<R>() * 64;
+                ck_next += T;
+            }
+        }
+    };
+    auto snapshot = [&](float *v) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r * 64] = cv[r];
+        v[R * 64] = dprev;
+    };
+
+    float4u ycur = *reinterpret_cast<const float4u *>(yp + e);
+    for (; e < col0 + e_pro; e += kStepsPerLoad) {
+        const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+        maybe_checkpoint();
+#pragma unroll
+        for (int u = 0; u < kStepsPerLoad; ++u) dp_step<R, false, false, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+        ycur = ynext;
+    }
+    for (int col = col0; col < col_end;) {
+        if (col == col_real && vin) snapshot(vin);
+        const int wl = min(qlen, rlen - col);
+        const int nb = wl >> 2, rm = wl & 3;
+        float wmin = INFINITY;
+        auto track = [&]() {
+            const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
+            wmin = fminf(wmin, cl);
+        };
+        auto block = [&](const float4u &yv) {
+            maybe_checkpoint();
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad; ++u) {
+                dp_step<R, false, false, int>(cv, sv, dprev, sdprev, x, yv.v[u], t_begin + e + u, lane0, xc);
+                track();
+            }
+            e += kStepsPerLoad;
+        };
+        for (int b = 0; b < nb; ++b) {
+            const float4u yb = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
+            block(ycur);
+            ycur = yb;
+        }
+        if (rm) {
+            const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + rm);
+            maybe_checkpoint();
+#pragma unroll
+            for (int u = 0; u < kStepsPerLoad - 1; ++u) {
+                if (u < rm) {
+                    dp_step<R, false, false, int>(cv, sv, dprev, sdprev, x, ycur.v[u], t_begin + e + u, lane0, xc);
+                    track();
+                }
+            }
+            e += rm;
+            ycur = ynext;
+        }
+        if (col >= col_real) top.offer(wmin, col, -1, job);
+        col += wl;
+    }
+    if (vout) snapshot(vout);
+}
+
+template <int R, int I = 0>
+__device__ __forceinline__ void segment_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
+                                                 const float (&x)[R], bool lane0, Exchange &xc, Top2<false> &top, int job, float *ckp, int T,
+                                                 int col0, int col_real, int col_end, float *vin, float *vout) {
+    if constexpr (R > 16) {
+        sweep_segment<R, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, col0, col_real, col_end, vin, vout);
+    } else {
+        if (rq == I) {
+            sweep_segment<R, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, col0, col_real, col_end, vin, vout);
+        } else if constexpr (I + 1 < R) {
+            segment_dispatch<R, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, col0, col_real, col_end, vin, vout);
+        }
+    }
+}
+
+// how segment `seg` of a job of rlen columns looks for a quad of query length qlen (also used by the verify kernel)
+struct SegRange {
+    int col0, col_real, col_end;
+    bool empty, last;
+};
+__device__ __forceinline__ SegRange segment_range(int rlen, int qlen, int n_seg, int warm_windows, int seg) {
+    const int nwin = (rlen + qlen - 1) / qlen;
+    const int nw = (nwin + n_seg - 1) / n_seg;
+    const int w_real = seg * nw;
+    SegRange r;
+    r.empty = w_real >= nwin;
+    r.last = w_real + nw >= nwin;
+    r.col_real = w_real * qlen;
+    r.col0 = max(0, w_real - warm_windows) * qlen;
+    r.col_end = min(rlen, (w_real + nw) * qlen);
+    return r;
+}
+
+// wave-task = (quad, job, segment); cost-only subsequence DTW (small batches)
+template <int R, int L>
+__device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i) {
+    const int chunk = task_local / cd.n_quads;
+    const int quad_local = task_local - chunk * cd.n_quads;
+    const int quad = cd.quad_base + quad_local;
+    const int lane = threadIdx.x & 63;
+    const int g = lane & (L - 1);
+    const int slot = lane / L;
+    const int job = chunk / a.n_seg, seg = chunk - job * a.n_seg;
+    const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);
+    const int read = a.order[quad * 4 + slot];
+    const int lq = (qlen - 1) / R;
+    const int rq = (qlen - 1) - lq * R;
+    const int t_begin = sweep_begin(lq);
+    Top2<false> top;
+    top.init();
+    const int rlen = a.job_len[job];
+    const SegRange sr = segment_range(rlen, qlen, a.n_seg, a.warm_windows, seg);
+    if (!sr.empty) {
+        float x[R];
+        load_query_rows<R>(x, a, read, qlen, g);
+        Exchange xc;
+        xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
+        const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
+        const int64_t ck_total = T ? a.job_ck_off[a.n_jobs] : 0;
+        const float *yp = a.ref + a.job_off[job] - g + t_begin;
+        float *ckp = nullptr;
+        if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
+        float *vin = seg > 0 ? a.verify + verify_slot(a, quad, job, seg, 0) + lane : nullptr;
+        float *vout = !sr.last ? a.verify + verify_slot(a, quad, job, seg, 1) + lane : nullptr;
+        segment_dispatch<R>(a, yp, rlen, qlen, lq, rq, t_begin, x, g == 0, xc, top, job, ckp, T, sr.col0, sr.col_real, sr.col_end, vin, vout);
+    }
+    if (g == lq && read >= 0) {
+        const int64_t o = (static_cast<int64_t>(quad) * a.n_chunks + chunk) * 4 + slot;
+        a.p_best[o] = top.best;
+        a.p_second[o] = top.second;
+        a.p_end[o] = top.end;
+        a.p_job[o] = top.job;
+    }
+}
+
 // grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR (rows per lane) bounds the shapes
 // compiled in, so a batch without long queries does not pay the long variant's register budget.
 template <int MAXR, bool TRACK, bool STD>
@@ -454,17 +643,25 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES 
     const int tl = task - cd.task_base;
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
-#define SFA_SHAPE(RR, LL)                                                                   \
-    case (RR) * 256 + (LL):                                                                 \
-        if constexpr (MAXR >= (RR)) fill_body<RR, LL, TRACK, STD>(a, cd, tl, lds_f, lds_i); \
+#define SFA_SHAPE(RR, LL)                                                                    \
+    case (RR) * 256 + (LL):                                                                  \
+        if constexpr (MAXR >= (RR)) {                                                        \
+            if constexpr (!TRACK && !STD) {                                                  \
+                if (a.n_seg > 1) {                                                           \
+                    fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */ \
+                    break;                                                                   \
+                }                                                                            \
+            }                                                                                \
+            fill_body<RR, LL, TRACK, STD>(a, cd, tl, lds_f, lds_i);                          \
+        }                                                                                    \
         break;
     switch (cd.R * 256 + cd.lanes) {
         SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
         SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
         SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
         SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
+        SFA_SHAPE(4, 16)
         default:
-            fill_body<4, 16, TRACK, STD>(a, cd, tl, lds_f, lds_i);
             break;
     }
 #undef SFA_SHAPE
@@ -664,7 +861,27 @@ __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
     return static_cast<uint8_t>(q);
 }
 
-#ifdef SFA_DEFINE_FINALIZE_KERNEL  // a plain (non-template) kernel: defined in exactly one translation unit
+#ifdef SFA_DEFINE_FINALIZE_KERNEL  // plain (non-template) kernels: defined in exactly one translation unit
+// one wave per (quad, job, hand-over between segment s and s+1): the state the later segment assumed against the state
+// the earlier one reached
+__global__ void __launch_bounds__(256) sdtw_verify_kernel(const DpArgs a, const int n_quads_total) {
+    const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int per_quad = a.n_jobs * (a.n_seg - 1);
+    if (w >= static_cast<int64_t>(n_quads_total) * per_quad) return;
+    const int quad = static_cast<int>(w / per_quad), rest = static_cast<int>(w - static_cast<int64_t>(quad) * per_quad);
+    const int job = rest / (a.n_seg - 1), seg = rest - job * (a.n_seg - 1);
+    int ci = 0;
+    while (ci + 1 < a.n_cls && quad >= a.cls[ci + 1].quad_base) ++ci;
+    const int qlen = a.quad_qlen[quad];
+    const SegRange next = segment_range(a.job_len[job], qlen, a.n_seg, a.warm_windows, seg + 1);
+    if (next.empty) return;
+    const int lane = threadIdx.x & 63;
+    const float *out = a.verify + verify_slot(a, quad, job, seg, 1) + lane, *in = a.verify + verify_slot(a, quad, job, seg + 1, 0) + lane;
+    bool same = true;
+    for (int p = 0; p <= a.cls[ci].R; ++p) same = same && (__float_as_uint(out[p * 64]) == __float_as_uint(in[p * 64]));
+    if (!__all(same) && lane == 0) a.seg_fail[quad] = 1;
+}
+
 __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_reads) return;

@@ -124,6 +124,8 @@ struct sfa_ctx {
     int64_t opt_ev_parallel_peaks = 1;       // sfa_align_raw: wave-per-read peak picker where its result is certified
     int64_t opt_ev_parallel_prefix = 1;      // sfa_align_raw: wave-per-read prefix sums where they are provably exact
     int64_t opt_min_slice_reads = 65536;     // a batch is only cut into slices of at least this many reads
+    int64_t opt_segment_warm = 4;            // query lengths of warm-up in front of a segment
+    int64_t opt_column_segments = 0;         // 0 = auto, 1 = off, N = segments per job for small batches (sweep_segment)
     int64_t opt_lane_widening = 0;           // 0 = by batch size; 1, 2, 4 = fixed (rows per lane / w, lanes per read * w)
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
@@ -136,8 +138,10 @@ struct sfa_ctx {
     DevBuf d_ref, d_job_off, d_job_len, d_job_contig, d_job_strand, d_ref_len, d_ref_off;
 
     // per-batch scratch
+    DevBuf d_verify, d_segfail;
+    int64_t seg_reruns = 0;  // batches walked again because a segment hand-over did not verify
     DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_wscore, d_tst, d_ck, d_out;
-    PinBuf h_stage, h_out, h_small;
+    PinBuf h_stage, h_out, h_small, h_flags;
 
     // raw-signal path (sfa_align_raw)
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
@@ -145,6 +149,7 @@ struct sfa_ctx {
 
     sfa_profile_t prof{};
     bool prof_pending = false;
+    bool no_segments_once = false;  // re-run of a batch whose segment hand-overs did not verify
     bool in_slice = false;   // align_device is running one slice of a cut-up batch
     int32_t pending_n = -1;  // reads of the batch submitted with sfa_submit_batch and not yet collected
 };
@@ -241,6 +246,9 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.trace_margin = c->opt_trace_margin;
     pp.lane_widening = c->opt_lane_widening;
     pp.widen_below = c->opt_widen_below;
+    pp.column_segments = c->opt_column_segments;
+    pp.segment_warm_windows = c->opt_segment_warm;
+    pp.allow_segments = !(c->flag & SFA_DTW) && !c->no_segments_once;
     sfa::BatchPlan plan;
     std::string perr;
     if (int rc = sfa::plan_batch(q_off, n, c->h_job_len, c->total_cols, pp, &plan, &perr)) return fail(rc, "%s", perr.c_str());
@@ -277,6 +285,13 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         return rc;
     if (plan.single_pass && (rc = c->d_pst.reserve(4 * n_part))) return rc;
     if (!plan.single_pass && plan.ck_floats > 0 && (rc = c->d_ck.reserve(sizeof(float) * plan.ck_floats))) return rc;
+    const int32_t verify_planes = plan.max_R + 1;
+    if (plan.n_seg > 1) {
+        const size_t vbytes = sizeof(float) * 64 * verify_planes * 2 * static_cast<size_t>(plan.n_seg) * n_jobs * std::max(n_quads, 1);
+        if ((rc = c->d_verify.reserve(vbytes)) || (rc = c->d_segfail.reserve(4 * static_cast<size_t>(std::max(n_quads, 1)))) ||
+            (rc = c->h_flags.reserve(4 * static_cast<size_t>(std::max(n_quads, 1)))))
+            return rc;
+    }
 
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_stage.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
@@ -317,6 +332,12 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.rev_query = ((c->flag & SFA_RNA) && !(c->flag & SFA_INV)) ? 1 : 0;
     da.ck_shift = plan.single_pass ? 0 : plan.ck_shift;
     da.trace_margin = plan.trace_margin;
+    da.n_seg = plan.n_seg;
+    da.warm_windows = plan.warm_windows;
+    da.n_jobs = n_jobs;
+    da.verify_planes = verify_planes;
+    da.verify = c->d_verify.as<float>();
+    da.seg_fail = c->d_segfail.as<int32_t>();
 
     FinalizeArgs fz{};
     fz.slot_of_read = reinterpret_cast<const int32_t *>(ds + o_slot);
@@ -345,6 +366,12 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         else
             launch_fill<false>(plan.max_R, std_dtw, da, st);
         KERNEL_TRY();
+        if (plan.n_seg > 1) {  // every hand-over between consecutive segments: assumed state == reached state?
+            HIP_TRY(hipMemsetAsync(c->d_segfail.p, 0, 4 * static_cast<size_t>(n_quads), st));
+            const int64_t waves = static_cast<int64_t>(n_quads) * n_jobs * (plan.n_seg - 1);
+            hipLaunchKernelGGL(sfa::sdtw_verify_kernel, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, st, da, n_quads);
+            KERNEL_TRY();
+        }
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));
     fz.mode = plan.single_pass ? 0 : 1;
@@ -372,7 +399,26 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     c->prof.ckpt_bytes = plan.single_pass ? 0 : static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
     c->prof.n_tasks = da.n_tasks;
     c->prof.n_chunks = n_chunks;
+    c->prof.n_segments = plan.n_seg;
+    c->prof.segment_reruns = c->seg_reruns;
     c->prof_pending = true;
+    if (plan.n_seg > 1 && n_quads > 0) {
+        // the verdict of the hand-over checks has to be known before anybody uses the rows: wait here (these are
+        // the small, latency-bound batches -- their caller is about to wait for them anyway)
+        int32_t *flags = c->h_flags.as<int32_t>();
+        HIP_TRY(hipMemcpyAsync(flags, c->d_segfail.p, 4 * static_cast<size_t>(n_quads), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool failed = false;
+        for (int32_t k = 0; k < n_quads && !failed; ++k) failed = flags[k] != 0;
+        if (failed) {  // a guessed state was not the true one somewhere: the batch is walked again, unsegmented
+            c->no_segments_once = true;
+            const int rc2 = align_device(c, d_queries, q_off, n, d_out);
+            c->no_segments_once = false;
+            c->seg_reruns++;
+            c->prof.segment_reruns = c->seg_reruns;
+            return rc2;
+        }
+    }
     return SFA_OK;
 }
 
@@ -486,11 +532,12 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail})
         b->release();
     c->h_stage.release();
     c->h_out.release();
     c->h_small.release();
+    c->h_flags.release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -520,6 +567,12 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "min_slice_reads") {
         if (value < 1) return fail(SFA_EINVAL, "min_slice_reads must be >= 1");
         c->opt_min_slice_reads = value;
+    } else if (k == "segment_warm_windows") {
+        if (value < 0 || value > 64) return fail(SFA_EINVAL, "segment_warm_windows must be 0..64");
+        c->opt_segment_warm = value;
+    } else if (k == "column_segments") {
+        if (value < 0 || value > 16) return fail(SFA_EINVAL, "column_segments must be 0 (auto), 1 (off) or 2..16");
+        c->opt_column_segments = value;
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
         c->opt_widen_below = value;

@@ -58,6 +58,9 @@ struct PlanParams {
     int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
     int64_t lane_widening = 0;      // 0 = auto (by batch size), else 1, 2 or 4
     int64_t widen_below = 5;        // auto: widen (x4) when the batch has fewer than this many waves per SIMD
+    int64_t column_segments = 0;    // 0 = auto (small batches of the 64-lane shapes), 1 = off, N = N segments per job
+    int64_t segment_warm_windows = 4;  // windows (query lengths) a segment starts before its own first one
+    bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory) and single pass
 };
 
 struct PlanClass {
@@ -67,6 +70,7 @@ struct PlanClass {
 
 struct BatchPlan {
     int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, widening = 1, ck_shift = 0, trace_margin = 0;
+    int32_t n_seg = 1, warm_windows = 4;  // column segments per job (sdtw_kernels.hpp, sweep_segment)
     bool single_pass = false;
     int64_t ck_floats = 0, query_events = 0;
     std::vector<int32_t> order;         // [4*max(n_quads,1)] read per (quad,slot) or -1
@@ -186,10 +190,31 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
             for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + per - 1) / per; ++qd) p.quad_qlen[qd] = l;
         }
 
-    // chunk the job list only as far as needed to fill the machine
-    p.n_chunks = chunks_for(n_quads);
-    p.chunk_begin.resize(p.n_chunks + 1);
-    split_jobs(job_len, total_cols, p.n_chunks, p.chunk_begin.data());
+    // column segments: when even one wave per (read, job) leaves the chip idle, every job is cut into segments that
+    // start from a guessed state a few windows early and are verified against their predecessor (sweep_segment)
+    if (pp.allow_segments && !pp.single_pass && p.widening == 4 && p.max_lanes == 64 && n_quads > 0) {
+        int32_t min_len = n_jobs ? job_len[0] : 0;
+        for (int32_t j = 1; j < n_jobs; ++j) min_len = std::min(min_len, job_len[j]);
+        const int64_t tasks = static_cast<int64_t>(n_quads) * n_jobs;
+        int64_t S = pp.column_segments > 0 ? pp.column_segments : (6 * pp.n_sims + tasks - 1) / tasks;
+        S = std::min<int64_t>(S, 16);
+        S = std::min<int64_t>(S, min_len / (4 * std::max<int64_t>(pp.segment_warm_windows, 1) * std::max(maxq, 1)));  // a segment at least four warm-ups long
+        // measured (nCoV, q = 250): 64 reads 1.94 -> 0.58 ms, 512 reads 2.0 -> 1.0 ms, 1 024 reads 2.2 -> 1.8 ms per batch; with
+        // two segments the warm-up costs more than the shorter chain saves
+        if (S >= 3 || (pp.column_segments > 1 && S >= 2)) p.n_seg = static_cast<int32_t>(S);
+        p.warm_windows = static_cast<int32_t>(pp.segment_warm_windows);
+    }
+    if (p.n_seg > 1) {  // chunk = (job, segment)
+        p.n_chunks = n_jobs * p.n_seg;
+        p.chunk_begin.resize(p.n_chunks + 1);
+        for (int32_t c = 0; c < p.n_chunks; ++c) p.chunk_begin[c] = c / p.n_seg;  // (the segmented kernels do not read it)
+        p.chunk_begin[p.n_chunks] = n_jobs;
+    } else {
+        // chunk the job list only as far as needed to fill the machine
+        p.n_chunks = chunks_for(n_quads);
+        p.chunk_begin.resize(p.n_chunks + 1);
+        split_jobs(job_len, total_cols, p.n_chunks, p.chunk_begin.data());
+    }
 
     // checkpoint interval
     p.job_ck_off.assign(n_jobs + 1, 0);

@@ -341,6 +341,50 @@ def test_context_lifecycle_does_not_leak():
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
 
 
+def test_column_segments_and_their_fallback(oracle):
+    """Small batches cut every strand into segments that start from a guessed state and are accepted only when the state
+    at the hand-over equals the state the previous segment reached.  With the normal warm-up they verify; with no warm-up
+    at all they cannot, and the batch is walked again unsegmented -- same rows either way."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=96, seed=17)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16)
+    with S.Aligner(ref, flag) as al:
+        rows = al.align_db(q, q_off)
+        p = al.profile()
+        assert p["n_segments"] >= 3 and p["segment_reruns"] == 0 and p["n_chunks"] == 2 * p["n_segments"]
+        assert_rows_equal(rows, want)
+        for seg in (2, 5, 16):
+            al.set_option("column_segments", seg)
+            assert al.align_db(q, q_off).tobytes() == rows.tobytes() and al.profile()["segment_reruns"] == 0
+        al.set_option("column_segments", 1)
+        assert al.align_db(q, q_off).tobytes() == rows.tobytes() and al.profile()["n_segments"] == 1
+        al.set_option("column_segments", 6)
+        al.set_option("segment_warm_windows", 0)      # the guess is used as is: the hand-over check must catch it
+        assert al.align_db(q, q_off).tobytes() == rows.tobytes()
+        assert al.profile()["segment_reruns"] == 1
+        al.set_option("ckpt_interval", 64)              # dense checkpoints across segment boundaries, pass 2 from any of them
+        al.set_option("segment_warm_windows", 4)
+        al.set_option("trace_margin", 0)
+        assert al.align_db(q, q_off).tobytes() == rows.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_column_segments_on_tie_heavy_data(oracle, seed):
+    """Quantised levels (exact ties everywhere), ragged query lengths, a short warm-up: whatever verifies is right,
+    whatever does not is re-run."""
+    rng = np.random.default_rng(300 + seed)
+    lens = [int(x) for x in rng.integers(3000, 9000, size=2)]
+    ref = _small_ref(rng, lens, False, quant=True)
+    qlens = rng.choice([0, 7, 25, 63, 64, 65, 100, 128, 129, 250, 256, 300, 512], size=40)
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = (rng.integers(-6, 7, int(q_off[-1])) / 4).astype(np.float32)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), 0, threads=8)
+    with S.Aligner(ref, 0) as al:
+        for seg, warm in ((0, 4), (4, 1), (8, 2), (3, 0)):
+            al.set_option("column_segments", seg)
+            al.set_option("segment_warm_windows", warm)
+            assert_rows_equal(al.align_db(q, q_off), want)
+
+
 def test_non_finite_queries_do_not_hang():
     """NaN / inf query values are outside the contract (the reference is undefined there); the call must still return."""
     ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=16, seed=2)

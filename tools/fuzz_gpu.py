@@ -49,6 +49,9 @@ def main():
         if rng.integers(0, 5) == 0:
             opts["single_pass"] = 1
         opts["lane_widening"] = int(rng.choice([0, 1, 1, 2, 4]))  # small batches widen by themselves; pin the other shapes too
+        if rng.integers(0, 2):  # column segments (small batches): forced counts and short warm-ups exercise the hand-over check
+            opts["column_segments"] = int(rng.choice([1, 2, 3, 8, 16]))
+            opts["segment_warm_windows"] = int(rng.choice([0, 1, 2, 4]))
         with S.Aligner(ref, flag) as al:
             for k, v in opts.items():
                 al.set_option(k, v)
