@@ -11,6 +11,8 @@ SFA_FOR_MAXR(SFA_FILL_DECL, false, false)
 SFA_FOR_MAXR(SFA_FILL_DECL, false, true)
 SFA_FOR_MAXR(SFA_FILL_DECL, true, false)
 SFA_FOR_MAXR(SFA_FILL_DECL, true, true)
+#define SFA_SEG_DECL(MR, ...) extern template __global__ void sdtw_fill_kernel<MR, false, false, true>(const DpArgs);
+SFA_FOR_MAXR(SFA_SEG_DECL, 0)
 SFA_FOR_MAXR(SFA_TRACE_DECL, false)
 SFA_FOR_MAXR(SFA_TRACE_DECL, true)
 }  // namespace sfa

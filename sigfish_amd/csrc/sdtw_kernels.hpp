@@ -632,8 +632,11 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 
 // grid: ceil(n_tasks/4) blocks of 256 threads (4 waves, one task each).  MAXR (rows per lane) bounds the shapes
 // compiled in, so a batch without long queries does not pay the long variant's register budget.
-template <int MAXR, bool TRACK, bool STD>
+// SEG: the column-segment variant (cost-only sDTW, small batches) is its own kernel, so that the throughput kernel's code
+// is not touched by it.
+template <int MAXR, bool TRACK, bool STD, bool SEG = false>
 __global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES))) sdtw_fill_kernel(const DpArgs a) {
+    static_assert(!SEG || (!TRACK && !STD), "segments: cost-only subsequence DTW");
     const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
     if (task >= a.n_tasks) return;  // wave-uniform
@@ -646,13 +649,10 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES 
 #define SFA_SHAPE(RR, LL)                                                                    \
     case (RR) * 256 + (LL):                                                                  \
         if constexpr (MAXR >= (RR)) {                                                        \
-            if constexpr (!TRACK && !STD) {                                                  \
-                if (a.n_seg > 1) {                                                           \
-                    fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */ \
-                    break;                                                                   \
-                }                                                                            \
-            }                                                                                \
-            fill_body<RR, LL, TRACK, STD>(a, cd, tl, lds_f, lds_i);                          \
+            if constexpr (SEG)                                                               \
+                fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */   \
+            else                                                                             \
+                fill_body<RR, LL, TRACK, STD>(a, cd, tl, lds_f, lds_i);                      \
         }                                                                                    \
         break;
     switch (cd.R * 256 + cd.lanes) {

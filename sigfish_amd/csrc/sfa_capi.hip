@@ -165,6 +165,17 @@ static_assert(sizeof(ResultRow) == sizeof(sfa_result_t), "result row layout");
 template <bool TRACK>
 void launch_fill(int maxr, bool std_dtw, const DpArgs &a, hipStream_t st) {
     const dim3 grid((a.n_tasks + 3) / 4), block(256);
+    if (!TRACK && a.n_seg > 1) {  // column segments (cost-only sDTW, small batches): the SEG kernels
+        if (maxr >= 32)
+            hipLaunchKernelGGL((sfa::sdtw_fill_kernel<32, false, false, true>), grid, block, 0, st, a);
+        else if (maxr >= 16)
+            hipLaunchKernelGGL((sfa::sdtw_fill_kernel<16, false, false, true>), grid, block, 0, st, a);
+        else if (maxr >= 8)
+            hipLaunchKernelGGL((sfa::sdtw_fill_kernel<8, false, false, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, true>), grid, block, 0, st, a);
+        return;
+    }
 #define SFA_FILL(MR)                                                                                   \
     if (std_dtw)                                                                                       \
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<MR, TRACK, true>), grid, block, 0, st, a);           \
