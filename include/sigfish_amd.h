@@ -144,8 +144,8 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
  * checkpoints would not fit the budget at the shortest interval is cut into slices of at least this many reads, run
  * back to back; default 65536), "ev_parallel_prefix" (sfa_align_raw: 1 = wave-per-read prefix sums for every read
  * whose sums are provably exact in any order, the sequential kernel for the rest; 0 = sequential for all),
- * "column_segments" (0 = auto: small batches cut every (contig,strand) sweep into up to 16 verified segments, 1 = off,
- * 2..16 = that many), "segment_warm_windows" (query lengths a segment starts early; default 4),
+ * "column_segments" (0 = auto: small batches cut every (contig,strand) sweep into up to 64 verified segments, 1 = off,
+ * 2..64 = that many), "segment_warm_windows" (query lengths a segment starts early; default 4),
  * "ev_parallel_peaks" (the same for the peak picker: 1 = chunk-parallel walk accepted where it is certified to equal the
  * sequential one). */
 int sfa_set_option(sfa_ctx_t *ctx, const char *key, int64_t value);

@@ -582,7 +582,7 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
         if (value < 0 || value > 64) return fail(SFA_EINVAL, "segment_warm_windows must be 0..64");
         c->opt_segment_warm = value;
     } else if (k == "column_segments") {
-        if (value < 0 || value > 16) return fail(SFA_EINVAL, "column_segments must be 0 (auto), 1 (off) or 2..16");
+        if (value < 0 || value > 64) return fail(SFA_EINVAL, "column_segments must be 0 (auto), 1 (off) or 2..64");
         c->opt_column_segments = value;
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");

@@ -197,7 +197,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         for (int32_t j = 1; j < n_jobs; ++j) min_len = std::min(min_len, job_len[j]);
         const int64_t tasks = static_cast<int64_t>(n_quads) * n_jobs;
         int64_t S = pp.column_segments > 0 ? pp.column_segments : ((pp.widen_below + 1) * pp.n_sims + tasks - 1) / tasks;  // a caller with several batches in flight lowers widen_below
-        S = std::min<int64_t>(S, 16);
+        S = std::min<int64_t>(S, 64);
         S = std::min<int64_t>(S, min_len / (4 * std::max<int64_t>(pp.segment_warm_windows, 1) * std::max(maxq, 1)));  // a segment at least four warm-ups long
         // measured (nCoV, q = 250): 64 reads 1.94 -> 0.58 ms, 512 reads 2.0 -> 1.0 ms, 1 024 reads 2.2 -> 1.8 ms per batch; with
         // two segments the warm-up costs more than the shorter chain saves

@@ -352,7 +352,7 @@ def test_column_segments_and_their_fallback(oracle):
         p = al.profile()
         assert p["n_segments"] >= 3 and p["segment_reruns"] == 0 and p["n_chunks"] == 2 * p["n_segments"]
         assert_rows_equal(rows, want)
-        for seg in (2, 5, 16):
+        for seg in (2, 5, 16, 64):
             al.set_option("column_segments", seg)
             assert al.align_db(q, q_off).tobytes() == rows.tobytes() and al.profile()["segment_reruns"] == 0
         al.set_option("column_segments", 1)
