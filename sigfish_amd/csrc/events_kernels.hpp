@@ -584,7 +584,7 @@ struct QueryArgs {
 
 // One wave per read: the window's means are staged in LDS with coalesced loads, lane 0 accumulates the two sequential
 // fp32 sums out of LDS (their order is what makes the result the reference's), all lanes normalise and store.
-constexpr int kQueryStage = 2048;  // = SFA_MAX_QUERY events
+constexpr int kQueryStage = 2048;  // = SFA_MAX_QUERY events; longer windows (row strips) are read from HBM directly
 
 __global__ void __launch_bounds__(64) ev_query_kernel(const QueryArgs a) {
     __shared__ float m[kQueryStage];
@@ -594,15 +594,21 @@ __global__ void __launch_bounds__(64) ev_query_kernel(const QueryArgs a) {
     const int len = static_cast<int>(a.q_off[i + 1] - o);
     if (len <= 0) return;
     const float *src = a.ev_mean + a.ev_off[i] + a.qstart[i];
-    for (int j = lane; j < len; j += 64) m[j] = src[j];
+    const bool staged = len <= kQueryStage;  // block-uniform
+    if (staged)
+        for (int j = lane; j < len; j += 64) m[j] = src[j];
     __syncthreads();
     if (lane == 0) {
         const float cnt = static_cast<float>(len);
         float mean = 0.0f, var = 0.0f;
-        for (int j = 0; j < len; ++j) mean += m[j];
+        if (staged) {
+            for (int j = 0; j < len; ++j) mean += m[j];
+        } else {
+            for (int j = 0; j < len; ++j) mean += src[j];
+        }
         mean /= cnt;
         for (int j = 0; j < len; ++j) {
-            const float dv = m[j] - mean;
+            const float dv = (staged ? m[j] : src[j]) - mean;
             var += dv * dv;
         }
         var /= cnt;
@@ -611,7 +617,7 @@ __global__ void __launch_bounds__(64) ev_query_kernel(const QueryArgs a) {
     }
     __syncthreads();
     const float mean = stat[0], sd = stat[1];
-    for (int j = lane; j < len; j += 64) a.queries[o + j] = (m[j] - mean) / sd;
+    for (int j = lane; j < len; j += 64) a.queries[o + j] = ((staged ? m[j] : src[j]) - mean) / sd;
 }
 
 // The query window's event table in the layout of event_t / sfa_event_t (src/sigfish.h:57-64), means z-normalised, for

@@ -22,6 +22,7 @@
 #include "sdtw_kernels.hpp"
 #include "events_kernels.hpp"
 #include "sdtw_instances.hpp"
+#include "sdtw_strips.hpp"
 #include "sfa_plan.hpp"
 
 namespace {
@@ -114,7 +115,7 @@ struct sfa_ctx {
     int device = 0;
     uint32_t flag = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end, row strips start
     int cu_count = 256;
 
     // tunables (sfa_set_option)
@@ -139,6 +140,9 @@ struct sfa_ctx {
 
     // per-batch scratch
     DevBuf d_verify, d_segfail;
+    DevBuf d_bndc, d_bnds, d_long, d_lbest, d_lsecond, d_lend, d_lst;  // row strips (queries beyond SFA_MAX_QUERY, sdtw_strips.hpp)
+    PinBuf h_long;
+    bool long_pending = false;
     int64_t seg_reruns = 0;  // batches walked again because a segment hand-over did not verify
     DevBuf d_queries, d_stage, d_pbest, d_pend, d_pst, d_pjob, d_psecond, d_wjob, d_wend, d_wscore, d_tst, d_ck, d_out;
     PinBuf h_stage, h_out, h_small, h_flags;
@@ -215,6 +219,82 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
 int resolve_profile(sfa_ctx *c);
 int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out);
 
+// Reads of more than SFA_MAX_QUERY events: one wave per (read, job) sweeps the query in strips of 2048 rows, handing the
+// last row of a strip to the next one through HBM (sdtw_strips.hpp).  Runs after the wave kernels of the batch, on the same
+// stream, and overwrites the (invalid) rows they left for these reads.  Reads are taken in groups whose boundary rows fit
+// the checkpoint budget.
+int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const std::vector<int32_t> &reads, ResultRow *d_out) {
+    const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
+    const size_t o_reads = 0, o_bnd = (sizeof(int32_t) * n_long + 7) & ~size_t(7);
+    const size_t stage_bytes = o_bnd + sizeof(int64_t) * (n_jobs + 1);
+    int rc;
+    if ((rc = c->h_long.reserve(stage_bytes)) || (rc = c->d_long.reserve(stage_bytes))) return rc;
+    char *hs = c->h_long.as<char>();
+    memcpy(hs + o_reads, reads.data(), sizeof(int32_t) * n_long);
+    int64_t *bnd_off = reinterpret_cast<int64_t *>(hs + o_bnd);
+    int64_t per = 0;
+    for (int32_t j = 0; j < n_jobs; ++j) {
+        bnd_off[j] = per;
+        per += (static_cast<int64_t>(c->h_job_len[j]) + sfa::kBndPad + 3) & ~int64_t(3);
+    }
+    bnd_off[n_jobs] = per;
+    const int64_t bytes_per_read = per * 2 * 8;  // two buffers of (cost, start column) per column
+    const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(n_long, c->opt_ckpt_budget / std::max<int64_t>(bytes_per_read, 1))));
+    const size_t n_part = static_cast<size_t>(n_long) * n_jobs;
+    if ((rc = c->d_bndc.reserve(sizeof(float) * 2 * per * group)) || (rc = c->d_bnds.reserve(sizeof(int32_t) * 2 * per * group)) ||
+        (rc = c->d_lbest.reserve(4 * n_part)) || (rc = c->d_lsecond.reserve(4 * n_part)) || (rc = c->d_lend.reserve(4 * n_part)) ||
+        (rc = c->d_lst.reserve(4 * n_part)))
+        return rc;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_long.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
+    const char *ds = c->d_long.as<char>();
+    const bool std_dtw = (c->flag & SFA_DTW) != 0;
+    for (int32_t g0 = 0; g0 < n_long; g0 += group) {
+        const int32_t gn = std::min(group, n_long - g0);
+        sfa::StripArgs sa{};
+        sa.queries = d_queries;
+        sa.q_off = d_q_off;
+        sa.reads = reinterpret_cast<const int32_t *>(ds + o_reads) + g0;
+        sa.ref = c->d_ref.as<float>();
+        sa.job_off = c->d_job_off.as<int64_t>();
+        sa.job_len = c->d_job_len.as<int32_t>();
+        sa.bnd_off = reinterpret_cast<const int64_t *>(ds + o_bnd);
+        sa.bnd_cost = c->d_bndc.as<float>();
+        sa.bnd_start = c->d_bnds.as<int32_t>();
+        sa.p_best = c->d_lbest.as<float>() + static_cast<size_t>(g0) * n_jobs;
+        sa.p_second = c->d_lsecond.as<float>() + static_cast<size_t>(g0) * n_jobs;
+        sa.p_end = c->d_lend.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
+        sa.p_st = c->d_lst.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
+        sa.n_long = gn;
+        sa.n_jobs = n_jobs;
+        sa.rev_query = ((c->flag & SFA_RNA) && !(c->flag & SFA_INV)) ? 1 : 0;
+        const int64_t tasks = static_cast<int64_t>(gn) * n_jobs;
+        const dim3 grid(static_cast<unsigned>((tasks + 3) / 4)), block(256);
+        if (std_dtw)
+            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<true>), grid, block, 0, st, sa);
+        else
+            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<false>), grid, block, 0, st, sa);
+        KERNEL_TRY();
+        sfa::StripFinalizeArgs fa{};
+        fa.reads = sa.reads;
+        fa.p_best = sa.p_best;
+        fa.p_second = sa.p_second;
+        fa.p_end = sa.p_end;
+        fa.p_st = sa.p_st;
+        fa.job_contig = c->d_job_contig.as<int32_t>();
+        fa.job_strand = c->d_job_strand.as<int8_t>();
+        fa.ref_len = c->d_ref_len.as<int32_t>();
+        fa.ref_st_offset = c->d_ref_off.as<int32_t>();
+        fa.out = d_out;
+        fa.n_long = gn;
+        fa.n_jobs = n_jobs;
+        hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, dim3((gn + 63) / 64), dim3(64), 0, st, fa);
+        KERNEL_TRY();
+        c->prof.fill_launches++;
+    }
+    return SFA_OK;
+}
+
 // A batch so large that its checkpoints only fit the budget at a long interval (a long pass 2) is cut into slices
 // of contiguous reads that keep the interval short; slices of >= 64 Ki reads still fill the chip.  Slices run one
 // after the other (each is planned and staged on its own), so such a call is synchronous.
@@ -260,6 +340,14 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.column_segments = c->opt_column_segments;
     pp.segment_warm_windows = c->opt_segment_warm;
     pp.allow_segments = !(c->flag & SFA_DTW) && !c->no_segments_once;
+    std::vector<int32_t> long_reads;  // queries beyond the wave kernels' 2048 events: row strips, after the rest of the batch
+    int64_t long_events = 0;
+    for (int32_t i = 0; i < n; ++i)
+        if (q_off[i + 1] - q_off[i] > sfa::kMaxQuery) {
+            long_reads.push_back(i);
+            long_events += q_off[i + 1] - q_off[i];
+        }
+    pp.skip_long = !long_reads.empty();
     sfa::BatchPlan plan;
     std::string perr;
     if (int rc = sfa::plan_batch(q_off, n, c->h_job_len, c->total_cols, pp, &plan, &perr)) return fail(rc, "%s", perr.c_str());
@@ -402,10 +490,15 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     } else {
         HIP_TRY(hipEventRecord(c->ev[3], st));
     }
+    c->prof.fill_launches = n_quads > 0 ? 1 : 0;
+    c->long_pending = !long_reads.empty();
+    if (c->long_pending) {
+        HIP_TRY(hipEventRecord(c->ev[5], st));
+        if ((rc = align_long(c, d_queries, da.q_off, long_reads, d_out))) return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev[4], st));
 
-    c->prof.cells = plan.query_events * c->total_cols;
-    c->prof.fill_launches = n_quads > 0 ? 1 : 0;
+    c->prof.cells = (plan.query_events + long_events) * c->total_cols;
     c->prof.ckpt_interval = plan.single_pass ? 0 : (plan.ck_shift ? (1 << plan.ck_shift) : 0);
     c->prof.ckpt_bytes = plan.single_pass ? 0 : static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
     c->prof.n_tasks = da.n_tasks;
@@ -441,6 +534,12 @@ int resolve_profile(sfa_ctx *c) {
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     HIP_TRY(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
     HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[4]));
+    if (c->long_pending) {  // the row-strip sweeps of long queries are fills
+        float l = 0;
+        HIP_TRY(hipEventElapsedTime(&l, c->ev[5], c->ev[4]));
+        a += l;
+        c->long_pending = false;
+    }
     c->prof.fill_ms = a;
     c->prof.trace_ms = d;
     c->prof.finalize_ms = t - a - d;
@@ -543,12 +642,13 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lst})
         b->release();
     c->h_stage.release();
     c->h_out.release();
     c->h_small.release();
     c->h_flags.release();
+    c->h_long.release();
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -819,7 +919,6 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
     HIP_TRY(hipMemcpyAsync(c->e_qoff.p, q_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
     sfa::QueryArgs qa{c->e_evmean.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(), c->e_qoff.as<int64_t>(),
                       c->d_queries.as<float>(), n};
-    static_assert(sfa::kQueryStage >= SFA_MAX_QUERY, "query staging");
     hipLaunchKernelGGL(sfa::ev_query_kernel, dim3(n), dim3(64), 0, st, qa);  // one wave per read
     sfa::BoundsArgs ba{c->e_evstart.as<int32_t>(), c->e_evlen.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(),
                        c->e_qoff.as<int64_t>(), c->e_b0.as<int32_t>(), c->e_b1.as<int32_t>(), c->e_b2.as<float>(), n};

@@ -61,6 +61,7 @@ struct PlanParams {
     int64_t column_segments = 0;    // 0 = auto (small batches of the 64-lane shapes), 1 = off, N = N segments per job
     int64_t segment_warm_windows = 4;  // windows (query lengths) a segment starts before its own first one
     bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory) and single pass
+    bool skip_long = false;         // true: reads of more than kMaxQuery events are left out (the caller runs them in row strips, sdtw_strips.hpp)
 };
 
 struct PlanClass {
@@ -102,7 +103,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     p = BatchPlan();
     p.single_pass = pp.single_pass;
     const int32_t n_jobs = static_cast<int32_t>(job_len.size());
-    std::vector<int32_t> qlen(n);
+    std::vector<int32_t> qlen(n, 0);
     int maxq = 0;
     for (int32_t i = 0; i < n; ++i) {
         const int64_t l = q_off[i + 1] - q_off[i];
@@ -110,6 +111,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
             *err = "q_off is not monotone at read " + std::to_string(i);
             return -1;  // SFA_EINVAL
         }
+        if (l > kMaxQuery && pp.skip_long) continue;  // qlen stays 0: planned like a read without events
         if (l > kMaxQuery) {
             *err = "read " + std::to_string(i) + " has " + std::to_string(l) + " events; the limit is " + std::to_string(kMaxQuery);
             return -4;  // SFA_ERANGE

@@ -139,6 +139,57 @@ def test_long_queries(oracle, seed, mode, gpu_mode):
     assert_rows_equal(got, want)
 
 
+@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "auto"])
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
+def test_row_strips(oracle, seed, mode, gpu_mode):
+    """`-q` beyond 2048 events (the reference has no limit): row strips of 2048 query rows, one wave per (read, contig,
+    strand), mixed in one batch with every ordinary class; strip edges (2049, 4096, 4097), contigs shorter than the query
+    and shorter than a wave, exact ties from quantised levels."""
+    rng = np.random.default_rng(9000 + seed)
+    rna = mode != "dna"
+    flag = {"dna": 0, "rna": S.RNA, "rna_std": S.RNA | S.DTW, "rna_inv": S.RNA | S.INV}[mode]
+    quant = seed == 1
+    lens = [int(x) for x in rng.integers(600, 7000, size=int(rng.integers(1, 4)))] + [int(rng.integers(3, 60)), int(rng.integers(60, 500))]
+    ref = _small_ref(rng, lens, rna, quant)
+    qlens = rng.choice([0, 64, 250, 1000, 2048, 2049, 2100, 3000, 4095, 4096, 4097, 5000, 6500], size=int(rng.integers(3, 12)))
+    qlens[0] = [2049, 4096, 4097, 6500][seed]
+    if seed == 3:
+        qlens = qlens[qlens > 2048]  # a batch of long reads only
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = (rng.integers(-6, 7, int(q_off[-1])) / 4).astype(np.float32) if quant else rng.normal(size=int(q_off[-1])).astype(np.float32)
+    with _aligner(ref, flag, gpu_mode) as al:
+        got = al.align_db(q, q_off)
+        again = al.align_db(q, q_off)  # buffers reused
+    assert got.tobytes() == again.tobytes()
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=8)
+    assert_rows_equal(got, want)
+
+
+def test_row_strips_ncov_and_groups(oracle):
+    """q = 2500 and 5000 against the nCoV reference (both strands): noisy copies of reference stretches, so that real
+    alignments exist; then the same batch with a boundary-row budget that forces one read per launch."""
+    ref, flag, q250, off250, meta = synth.workload("ncov_r9_dna_q250", n_reads=8, seed=11)
+    rng = np.random.default_rng(13)
+    qlens = np.array([2500, 250, 5000, 2049, 1000])
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = np.empty(int(q_off[-1]), np.float32)
+    fw, rv = ref.forward[0], ref.reverse[0]
+    for i, l in enumerate(qlens):
+        src = fw if i % 2 == 0 else rv
+        st = int(rng.integers(0, len(src) - l))
+        seg = src[st:st + l] + rng.normal(scale=0.3, size=l).astype(np.float32)
+        q[q_off[i]:q_off[i + 1]] = ((seg - seg.mean()) / seg.std()).astype(np.float32)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16)
+    with S.Aligner(ref, flag) as al:
+        got = al.align_db(q, q_off)
+        assert_rows_equal(got, want)
+        assert (got["mapq"][[0, 2, 3]] > 0).all() and [chr(c) for c in got["strand"][[0, 2, 3]]] == ["+", "+", "-"]
+        al.set_option("ckpt_budget_bytes", 1 << 20)  # less than one read's boundary rows: groups of one read
+        assert al.align_db(q, q_off).tobytes() == got.tobytes()
+        assert al.profile()["fill_launches"] == 1 + 3
+
+
 def test_long_queries_ncov(oracle):
     """q = 1000 and 2000 against the nCoV reference (both strands), default checkpointing."""
     ref, flag, q250, off250, meta = synth.workload("ncov_r9_dna_q250", n_reads=8, seed=11)
@@ -417,6 +468,3 @@ def test_no_device_fallback_is_loud():
     ref = _small_ref(np.random.default_rng(0), [50], False)
     with pytest.raises(S.SfaError):
         S.Aligner(ref, 0, device=99)
-    with S.Aligner(ref, 0) as al:
-        with pytest.raises(S.SfaError):
-            al.align_db(np.zeros(2049, np.float32), np.array([0, 2049], np.int64))  # > SFA_MAX_QUERY
