@@ -58,6 +58,10 @@ CASES = [
     ("rna_sam", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "--sam"]),
     ("rna_q1000", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "1000", "--full-ref"]),
     ("rna_q2000_sam", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "2000", "--full-ref", "--sam"]),
+    # queries beyond 2048 events (row strips on the GPU side): 7 of the 8 reads have more than 2048 + 50 events
+    ("rna_q2500", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "2500"]),
+    ("rna_q4200_full_sam", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "4200", "--full-ref", "--sam"]),
+    ("rna_q3000_full_dtw_std", "rnasequin_sequences_2.4.fa", "sequin_rna.blow5", 5, ["--rna", "-q", "3000", "--full-ref", "--dtw-std"]),
 ]
 
 
@@ -207,8 +211,12 @@ def main():
         os.chmod(dst, 0o644)
     synth_levels(6, 1, 90, 12).tofile(os.path.join(GOLD, "models", "syn6.f32"))
     synth_levels(5, 2, 100, 14).tofile(os.path.join(GOLD, "models", "syn5.f32"))
+    only = sys.argv[1:]  # case names: regenerate just these (the other fixtures are left as they are)
     for c in CASES:
-        run_case(*c)
+        if not only or c[0] in only:
+            run_case(*c)
+    if only:
+        return
     kernel_vectors()
     eval_goldens()
     random_goldens()

@@ -41,7 +41,7 @@ def test_cli_matches_reference_output(name, models):
     assert r.stdout.decode() == c["out_text"]
 
 
-@pytest.mark.parametrize("name", ["dna_default", "dna_from_end", "rna_default", "rna_full_ref_dtw_std", "dna_sam", "rna_sam", "rna_q2000_sam"])
+@pytest.mark.parametrize("name", ["dna_default", "dna_from_end", "rna_default", "rna_full_ref_dtw_std", "dna_sam", "rna_sam", "rna_q2000_sam", "rna_q2500", "rna_q4200_full_sam"])
 def test_cli_host_events_path(name, models):
     """--host-events forces event detection onto host threads; output must be identical to the default (GPU) path."""
     c = load_case(name)
