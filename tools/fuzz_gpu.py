@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """fuzz_gpu.py -- randomised parity campaign of the HIP path against the oracle (run on an MI355X box):
 random reference shapes, ragged query lengths, DNA / RNA / std-DTW / invert, quantised values (exact ties),
-random checkpoint intervals, trace margins and lane shapes.  Usage: python tools/fuzz_gpu.py [iterations] [seed]"""
+random checkpoint intervals, trace margins and lane shapes.  Usage: python tools/fuzz_gpu.py [iterations] [seed] [long]
+(`long`: query lengths up to 9000 events, i.e. the row-strip path mixed with the wave kernels)"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from oracle import oracle as O  # noqa: E402
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    long_mode = len(sys.argv) > 3 and sys.argv[3] == "long"
     rng = np.random.default_rng(seed)
     t0 = time.time()
     bad = 0
@@ -34,9 +36,13 @@ def main():
         ref = S.RefModel([f"c{i}" for i in range(nref)], [n + 5 for n in lens], lens, rng.integers(0, 4, nref) if rna else [0] * nref, fw, rv)
         n = int(rng.integers(1, 70))
         qmax = int(rng.choice([30, 64, 128, 250, 256, 512, 512, 700, 1024, 1100, 2048]))
+        if long_mode:
+            qmax = int(rng.choice([2049, 2100, 3000, 4096, 4097, 4100, 6200, 9000]))
         if qmax > 512:
-            n = min(n, 24)  # keeps the oracle's matrices (one per thread) small
+            n = min(n, 24 if qmax <= 2048 else 10)  # keeps the oracle's matrices (one per thread) small
         qlens = rng.integers(0, qmax + 1, size=n)
+        if long_mode:
+            qlens[0] = qmax
         if rng.integers(0, 3) == 0:
             qlens[:] = qmax
         q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)

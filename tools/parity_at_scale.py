@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """parity_at_scale.py -- the HIP path against THE REFERENCE ITSELF (oracle/_ref/ref_bench: the reference's own align_db
 compiled from its sources) on thousands of synthetic reads per BASELINE workload shape.  Run on an MI355X box:
-    python tools/parity_at_scale.py [scale]     (scale 1.0 ~ 4 minutes of host CPU on 16 cores)
+    python tools/parity_at_scale.py [scale [workload:reads ...]]     (scale 1.0 ~ 5 minutes of host CPU on 16 cores)
 TEST TOOLING: it loads oracle/ and is not part of the product."""
 import os
 import sys
@@ -19,7 +19,10 @@ def main():
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     cores = len(os.sched_getaffinity(0))
     plan = [("ncov_r9_dna_q250", 20000), ("sequin_r9_rna_q250", 20000), ("rna004_fullref_dtwstd_q250", 5000),
-            ("r10_dna_1mb_q250", 96), ("ncov_r9_dna_q1000", 3000), ("ncov_r9_dna_q2000", 1500)]
+            ("r10_dna_1mb_q250", 96), ("ncov_r9_dna_q1000", 3000), ("ncov_r9_dna_q2000", 1500),
+            ("ncov_r9_dna_q3000", 600), ("ncov_r9_dna_q5000", 300)]  # the last two: row strips (queries beyond 2048 events)
+    if len(sys.argv) > 2:  # workload:reads pairs instead of the whole plan
+        plan = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[2:]]
     bad_total = 0
     for wl, n in plan:
         n = max(8, int(n * scale))
