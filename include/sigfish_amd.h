@@ -38,11 +38,14 @@ enum {
     SFA_EINVAL = -1,  /* bad argument */
     SFA_ENODEV = -2,  /* no usable GPU / HIP error */
     SFA_ENOMEM = -3,  /* allocation failed */
-    SFA_ERANGE = -4,  /* query longer than SFA_MAX_QUERY */
+    SFA_ERANGE = -4,  /* a size out of range (output buffer too small; sfa_plan_batch: query beyond SFA_MAX_QUERY) */
     SFA_EKERNEL = -5  /* kernel launch or execution failed */
 };
 
-#define SFA_MAX_QUERY 2048 /* longest query (events) a single read may have */
+/* Queries of up to SFA_MAX_QUERY events are held in the registers of one wavefront (two-pass kernels).  Longer ones --
+ * the reference has no limit on -q (src/cdtw.c:171-189 fills whatever it is given) -- are accepted by every align entry
+ * point and run as row strips of SFA_MAX_QUERY query rows each (sdtw_strips.hpp), in the same call, same rows. */
+#define SFA_MAX_QUERY 2048
 
 /* Reference event model: the fields of refsynth_t (src/sigfish.h:90-99) the alignment stage reads. */
 typedef struct {
