@@ -6,18 +6,25 @@
 // wave sweeps one after the other over the same (contig,strand):
 //   * strip 0 is the ordinary sweep (row 0 has the free start of subsequence() or the cumulative first row of
 //     std_dtw());
-//   * the LAST row of every strip but the final one is written to HBM as it is produced -- cost and carried start
-//     column of every reference column, 8 bytes per column -- and is the "row above" of the next strip: lane 0 of the
-//     next sweep takes its `up` input (and, one step later, its diagonal input) from that row instead of the constant
-//     boundary;
+//   * the LAST row of every strip but the final one is written to HBM as it is produced, one value per reference
+//     column, and is the "row above" of the next strip: lane 0 of the next sweep takes its `up` input (and, one step
+//     later, its diagonal input) from that row instead of the constant boundary;
 //   * the final strip holds the last query row: the window scan of src/sigfish.c:891-901 / 938-948 and the top-2 of
-//     update_aln (src/sigfish.c:575-626) run there, with the start column tracked forward by the traceback rule of
-//     path() (diagonal, then left, then up; src/cdtw.c:134-146) exactly as in the single-pass kernels.
-// Every cell is still a pure function of its three neighbours in fp32, so the rows are bit-identical to the
-// reference's; the boundary rows are stored and re-read as the same 32-bit patterns.
-// One pass with tracking (7 VALU per cell instead of 3): a query of this length is 8x the default and rare; the strip
-// path trades the checkpoint machinery for simplicity.  HBM traffic: 16 bytes per column and strip boundary against
-// 2048 x 7 lane-operations -- nowhere near a bound.
+//     update_aln (src/sigfish.c:575-626) run there.
+// TWO PASSES, as in the wave kernels.  Pass 1 (sdtw_strip_kernel<STD, false>, one wave per (read, contig, strand)) evaluates
+// costs only -- v_sub, v_min3, v_add per cell -- keeps every window's minimum and drops a checkpoint of every strip's
+// anti-diagonal state (32 costs + the diagonal input per lane) every T steps; the strip finalize merges the per-job top-2
+// and names the winning (job, window, score).  Pass 2 (sdtw_strip_kernel<STD, true>, one wave per read) sweeps the WINNING
+// job again, all strips from the same checkpoint a query length (+64) before the winning window to the end of that window,
+// with the start column carried forward by the traceback rule of path() (diagonal, then left, then up;
+// src/cdtw.c:134-146), the boundary rows now holding (cost, start column); the first cell of the window whose cost equals
+// the winning score bit for bit is the reference's first strict minimum, and the start carried into it is where
+// subsequence_path() ends.  Restored cells carry start -1; if -1 reaches the winning cell the path began before the
+// checkpoint and the read backs off 1, 2, 4 ... checkpoints, ultimately to column 0.  Costs are restored bit-exactly and
+// both passes evaluate the same pure fp32 function of three neighbours per cell, so costs agree bit for bit with each
+// other and with the reference.
+// HBM traffic: 4 (pass 1) or 8 (pass 2) bytes per column and strip boundary + 8.4 KB per checkpoint and strip, against
+// 2048 x 3..7 lane-operations per column.
 #pragma once
 
 #include "sdtw_kernels.hpp"
@@ -37,22 +44,33 @@ struct StripArgs {
     const int32_t *job_len;   // [n_jobs]
     const int64_t *bnd_off;   // [n_jobs+1] word offset of job j's boundary row inside one buffer (multiples of 4)
     float *bnd_cost;          // [n_long][2 buffers][bnd_off[n_jobs]] last-row costs of the previous / current strip
-    int32_t *bnd_start;       // same, carried start columns
-    float *p_best, *p_second; // partial top-2 per (long read, job)
-    int32_t *p_end, *p_st;
+    int32_t *bnd_start;       // [n_long][2 buffers][bnd_row_max] carried start columns (pass 2: one job per read)
+    int64_t bnd_row_max;      // words of the longest boundary row
+    float *p_best, *p_second; // pass 1: partial top-2 per (long read, job); p_end = first column of the best window
+    int32_t *p_end;
+    const int32_t *w_job;     // pass 2: winner per long read (from the strip finalize): job, first column of the window, score
+    const int32_t *w_ws;
+    const float *w_score;
+    int32_t *t_st, *t_end;    // pass 2 out: start / end column of the winning alignment per long read
+    float *ck;                // checkpoints [n_long][ck_off[n_jobs]][33 planes][64 lanes]
+    const int64_t *ck_off;    // [n_jobs+1] prefix sum over jobs of max_strips * nck(job), nck(job) = (rlen - 1) >> ck_shift
+    int32_t ck_shift;         // checkpoint interval T = 1 << ck_shift steps (a multiple of the 4-step block)
+    int32_t max_strips;       // strips of the longest query of the launch
+    int32_t trace_margin;     // pass 2 resumes at least this many columns before the winning window; < 0: query length + 64
     int32_t n_long, n_jobs, rev_query;
 };
 
-// One anti-diagonal step of a strip: dp_step<32, TRACK = true> with the handling of query row 0 made conditional on
-// FIRST (the strip that contains it).
-template <bool STD, bool FIRST>
+// One anti-diagonal step of a strip: dp_step<32, TRACK> with the handling of query row 0 made conditional on FIRST (the
+// strip that contains it).
+template <bool STD, bool FIRST, bool TRACK>
 __device__ __forceinline__ void strip_step(typename Vec<float, kStripR>::type &c, typename Vec<int, kStripR>::type &s, float &dprev,
                                            int &sdprev, const float (&x)[kStripR], const float yv, const int t, const bool lane0,
                                            Exchange &xc) {
     float up = xc.shift(static_cast<float>(c[kStripR - 1]));
-    int sup = xc.shift(static_cast<int>(s[kStripR - 1]));
+    int sup = 0;
+    if (TRACK) sup = xc.shift(static_cast<int>(s[kStripR - 1]));
     if (STD && FIRST) {
-        if (t == 0) xc.template set_boundary<true>(lane0, INFINITY);  // std_dtw(): row 0 continues from its left neighbour only
+        if (t == 0) xc.template set_boundary<TRACK>(lane0, INFINITY);  // std_dtw(): row 0 continues from its left neighbour only
     }
     float diag = dprev;
     int sdiag = sdprev;
@@ -71,8 +89,11 @@ __device__ __forceinline__ void strip_step(typename Vec<float, kStripR>::type &c
             m = fminf(fminf(up, diag), left);
         }
         const float cn = fabsf(x[r] - yv) + m;
-        int sn = (diag == m) ? sdiag : ((left == m) ? sleft : sup);  // src/cdtw.c:134-146
-        if (FIRST && r == 0) sn = lane0 ? t : sn;                    // query row 0: the path starts in this column
+        int sn = 0;
+        if (TRACK) {
+            sn = (diag == m) ? sdiag : ((left == m) ? sleft : sup);  // src/cdtw.c:134-146
+            if (FIRST && r == 0) sn = lane0 ? t : sn;                // query row 0: the path starts in this column
+        }
         diag = left;
         sdiag = sleft;
         up = cn;
@@ -89,43 +110,77 @@ struct __attribute__((aligned(16))) float4a {
     float v[4];
 };
 
-// One strip of one (contig,strand).  `last`: the strip holds the last query row (lane lq, register rq).
-template <bool STD, bool FIRST>
-__device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int qlen, const bool last, const float (&x)[kStripR],
-                                            const int lq, const int rq, const int lane, Exchange &xc, const float *bin_c,
-                                            const int32_t *bin_s, float *bout_c, int32_t *bout_s, Top2<true> &top, const int job) {
+// What the final strip reports.  Pass 1: the running top-2 over windows (by window).  Pass 2: the winning cell.
+struct StripResult {
+    Top2<false> top;   // pass 1
+    int cap_end, cap_st;  // pass 2
+};
+
+// One strip over columns [0, ncols) of one (contig,strand).  `last`: the strip holds the last query row (lane lq,
+// register rq).  Pass 2 (TRACK): [ws, ncols) is the winning window and `best` its minimum.
+template <bool STD, bool FIRST, bool TRACK>
+__device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen, const bool last,
+                                            const float (&x)[kStripR], const int lq, const int rq, const int lane, Exchange &xc,
+                                            const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
+                                            const int job, const int ws, const float best, const int t_begin, float *ckp,
+                                            const int ck_shift, const int nck) {
+    // ckp: this strip's checkpoint records (+ lane).  Pass 1 stores record k - 1 before step k*T; pass 2 resumes from the
+    // record of step t_begin (t_begin = 0: from the initial state).
     typename Vec<float, kStripR>::type c;
     typename Vec<int, kStripR>::type s;
-#pragma unroll
-    for (int r = 0; r < kStripR; ++r) {
-        c[r] = INFINITY;
-        s[r] = 0;
-    }
     float dprev = INFINITY;
     int sdprev = 0;
+    if (TRACK && t_begin > 0) {  // exact costs; where these cells came from is unknown (-1)
+        const float *rec = ckp + static_cast<int64_t>((t_begin >> ck_shift) - 1) * ((kStripR + 1) * 64);
+#pragma unroll
+        for (int r = 0; r < kStripR; ++r) {
+            c[r] = rec[r * 64];
+            s[r] = -1;
+        }
+        dprev = rec[kStripR * 64];
+        sdprev = -1;
+    } else {
+#pragma unroll
+        for (int r = 0; r < kStripR; ++r) {
+            c[r] = INFINITY;
+            s[r] = 0;
+        }
+    }
     const bool lane0 = lane == 0;
-    if (FIRST) xc.template set_boundary<true>(lane0, 0.0f);
+    // std_dtw(): a sweep that resumes behind column 0 has the +inf boundary of its first row already
+    if (FIRST) xc.template set_boundary<TRACK>(lane0, (STD && t_begin > 0) ? INFINITY : 0.0f);
+    const int T = 1 << ck_shift;
+    const int ck_last = nck << ck_shift;
 
-    // window scan of the last row (final strip only), src/sigfish.c:891-901; std_dtw has the single candidate C[n-1][m-1]
+    // pass 1, final strip: window scan of the last row (src/sigfish.c:891-901) -- only the minimum of every window is kept,
+    // the window is named by its first column; std_dtw has the single candidate C[n-1][m-1]
     float wmin = INFINITY;
-    int wpos = -1, wst = -1;
+    int wcol0 = 0;
     int wend = min(qlen, rlen);
 
-    const int n_steps = rlen + lq;  // lane lq meets the last column at step rlen - 1 + lq
-    float4u ycur = *reinterpret_cast<const float4u *>(yp);
+    const int n_steps = ncols + lq;  // lane lq meets column ncols - 1 at step ncols - 1 + lq
+    float4u ycur = *reinterpret_cast<const float4u *>(yp + t_begin);
     float4a bc{};
     int4a bs{};
     if (!FIRST) {
-        bc = *reinterpret_cast<const float4a *>(bin_c);
-        bs = *reinterpret_cast<const int4a *>(bin_s);
+        bc = *reinterpret_cast<const float4a *>(bin_c + t_begin);
+        if (TRACK) bs = *reinterpret_cast<const int4a *>(bin_s + t_begin);
     }
-    for (int t0 = 0; t0 < n_steps; t0 += 4) {
+    for (int t0 = t_begin; t0 < n_steps; t0 += 4) {
+        if (!TRACK) {
+            if (t0 > 0 && (t0 & (T - 1)) == 0 && t0 <= ck_last) {  // wave-uniform: snapshot of the state before step t0
+                float *rec = ckp + static_cast<int64_t>((t0 >> ck_shift) - 1) * ((kStripR + 1) * 64);
+#pragma unroll
+                for (int r = 0; r < kStripR; ++r) rec[r * 64] = c[r];
+                rec[kStripR * 64] = dprev;
+            }
+        }
         const float4u ynext = *reinterpret_cast<const float4u *>(yp + t0 + 4);
         float4a bcn{};
         int4a bsn{};
         if (!FIRST) {
             bcn = *reinterpret_cast<const float4a *>(bin_c + t0 + 4);
-            bsn = *reinterpret_cast<const int4a *>(bin_s + t0 + 4);
+            if (TRACK) bsn = *reinterpret_cast<const int4a *>(bin_s + t0 + 4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -133,35 +188,34 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             if (!FIRST) {  // the row above query row 0 of this strip: column t of the previous strip's last row
                 if (lane0) {
                     *((Exchange::lds_vf *)xc.rf) = bc.v[u];
-                    *((Exchange::lds_vi *)xc.ri) = bs.v[u];
+                    if (TRACK) *((Exchange::lds_vi *)xc.ri) = bs.v[u];
                 }
             }
-            strip_step<STD, FIRST>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc);
+            strip_step<STD, FIRST, TRACK>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc);
             if (!last) {  // (wave-uniform) lane 63 is at column t - 63 of the strip's last row
                 const int col = t - 63;
-                if (lane == 63 && col >= 0 && col < rlen) {
+                if (lane == 63 && col >= 0 && col < ncols) {
                     bout_c[col] = c[kStripR - 1];
-                    bout_s[col] = s[kStripR - 1];
+                    if (TRACK) bout_s[col] = s[kStripR - 1];
                 }
             } else {
                 const int col = t - lq;  // wave-uniform
-                if (col >= 0 && col < rlen) {
+                if (col >= 0 && col < ncols) {
                     const float cl = c[rq];
-                    const int sl = s[rq];
-                    if (!STD) {
-                        const bool lt = cl < wmin;  // first strict minimum of the window
-                        wmin = lt ? cl : wmin;
-                        wpos = lt ? col : wpos;
-                        wst = lt ? sl : wst;
+                    if (TRACK) {  // first cell of the winning window that attains the winning score
+                        const bool hit = res.cap_end < 0 && col >= ws && cl == best;
+                        res.cap_end = hit ? col : res.cap_end;
+                        res.cap_st = hit ? static_cast<int>(s[rq]) : res.cap_st;
+                    } else if (!STD) {
+                        wmin = fminf(wmin, cl);
                         if (col + 1 == wend) {
-                            top.offer(wmin, wpos, wst, job);
+                            res.top.offer(wmin, wcol0, -1, job);
                             wmin = INFINITY;
-                            wpos = -1;
-                            wst = -1;
+                            wcol0 = wend;
                             wend = min(wend + qlen, rlen);
                         }
                     } else if (col == rlen - 1) {
-                        top.offer(cl, col, sl, job);
+                        res.top.offer(cl, col, -1, job);
                     }
                 }
             }
@@ -172,15 +226,24 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     }
 }
 
-// wave-task = (long read, job); 4 waves per block
-template <bool STD>
-__global__ void __launch_bounds__(256, 1) sdtw_strip_kernel(const StripArgs a) {
+// Pass 1 (TRACK = false): wave-task = (long read, job).  Pass 2 (TRACK = true): wave-task = long read, its winning job.
+// 4 waves per block.
+template <bool STD, bool TRACK>
+__global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const StripArgs a) {
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (task >= a.n_long * a.n_jobs) return;  // wave-uniform
-    const int job = task / a.n_long, li = task - job * a.n_long;  // job-major: neighbouring waves stream the same reference
+    if (task >= (TRACK ? a.n_long : a.n_long * a.n_jobs)) return;  // wave-uniform
+    int job, li;
+    if (TRACK) {
+        li = task;
+        job = a.w_job[li];
+        if (job < 0) return;  // nothing aligned (no candidate at all)
+    } else {
+        job = task / a.n_long;  // job-major: neighbouring waves stream the same reference
+        li = task - job * a.n_long;
+    }
     const int lane = threadIdx.x & 63;
     __shared__ float lds_f[4 * kXchWordsPerWave];
-    __shared__ int lds_i[4 * kXchWordsPerWave];
+    __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
     Exchange xc;
     xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
 
@@ -193,69 +256,116 @@ __global__ void __launch_bounds__(256, 1) sdtw_strip_kernel(const StripArgs a) {
     const float *yp = a.ref + a.job_off[job] - lane;  // this lane's column at step t is t - lane
     const int64_t per = a.bnd_off[a.n_jobs];
     float *bc = a.bnd_cost + static_cast<int64_t>(li) * 2 * per + a.bnd_off[job];
-    int32_t *bs = a.bnd_start + static_cast<int64_t>(li) * 2 * per + a.bnd_off[job];
+    int32_t *bs = TRACK ? a.bnd_start + static_cast<int64_t>(li) * 2 * a.bnd_row_max : nullptr;
 
-    Top2<true> top;
-    top.init();
+    int ws = 0, ncols = rlen;
+    float best = 0.0f;
+    const int nck = (rlen - 1) >> a.ck_shift;  // checkpoints per strip of this job
+    const int T = 1 << a.ck_shift;
+    int k = 0, back = 1;
+    if (TRACK) {
+        ws = a.w_ws[li];
+        best = a.w_score[li];
+        ncols = STD ? rlen : min(rlen, ws + qlen);  // columns up to the end of the winning window
+        // every cell of a path that starts at or behind column k*T is evaluated after step k*T in every strip; a path of
+        // qlen events rarely spans more than qlen columns -- and when it does, the read backs off
+        const int from = ws - (a.trace_margin >= 0 ? a.trace_margin : qlen + 64);
+        k = from > 0 ? min(from >> a.ck_shift, nck) : 0;
+    }
+    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * ((kStripR + 1) * 64) + lane;
+    StripResult res;
+    res.top.init();
     int lq = 0;
-    for (int sidx = 0; sidx < n_strips; ++sidx) {
-        const int row0 = sidx * kStripRows;
-        const int rows = min(kStripRows, qlen - row0);
-        const bool last = sidx == n_strips - 1;
-        lq = (rows - 1) / kStripR;
-        const int rq = (rows - 1) - lq * kStripR;
-        float x[kStripR];
+    for (int attempt = 0; attempt < 40; ++attempt) {  // pass 1: once; pass 2: until the start is known (k reaches 0 after <= 32 halvings)
+        res.cap_end = -1;
+        res.cap_st = -1;
+        for (int sidx = 0; sidx < n_strips; ++sidx) {
+            const int row0 = sidx * kStripRows;
+            const int rows = min(kStripRows, qlen - row0);
+            const bool last = sidx == n_strips - 1;
+            lq = (rows - 1) / kStripR;
+            const int rq = (rows - 1) - lq * kStripR;
+            float x[kStripR];
 #pragma unroll
-        for (int r = 0; r < kStripR; ++r) {
-            const int i = row0 + lane * kStripR + r;
-            const int src = a.rev_query ? (qlen - 1 - i) : i;
-            x[r] = (i < qlen) ? q[src] : 0.0f;
+            for (int r = 0; r < kStripR; ++r) {
+                const int i = row0 + lane * kStripR + r;
+                const int src = a.rev_query ? (qlen - 1 - i) : i;
+                x[r] = (i < qlen) ? q[src] : 0.0f;
+            }
+            float *bout_c = bc + (sidx & 1) * per;
+            const float *bin_c = bc + ((sidx & 1) ^ 1) * per;
+            int32_t *bout_s = TRACK ? bs + (sidx & 1) * a.bnd_row_max : nullptr;
+            const int32_t *bin_s = TRACK ? bs + ((sidx & 1) ^ 1) * a.bnd_row_max : nullptr;
+            float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
+            if (sidx == 0)
+                strip_sweep<STD, true, TRACK>(yp, rlen, ncols, qlen, last, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws, best,
+                                              k * T, ckp, a.ck_shift, nck);
+            else
+                strip_sweep<STD, false, TRACK>(yp, rlen, ncols, qlen, last, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws, best,
+                                               k * T, ckp, a.ck_shift, nck);
+            // the boundary row was stored by lane 63 and is loaded by every lane of the same wave in the next strip: complete
+            // the stores and drop the lines the vector cache may still hold from two strips ago
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        float *bout_c = bc + (sidx & 1) * per;
-        int32_t *bout_s = bs + (sidx & 1) * per;
-        const float *bin_c = bc + ((sidx & 1) ^ 1) * per;
-        const int32_t *bin_s = bs + ((sidx & 1) ^ 1) * per;
-        if (sidx == 0)
-            strip_sweep<STD, true>(yp, rlen, qlen, last, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, top, job);
-        else
-            strip_sweep<STD, false>(yp, rlen, qlen, last, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, top, job);
-        // the boundary row was stored by lane 63 and is loaded by every lane of the same wave in the next strip: complete
-        // the stores and drop the lines the vector cache may still hold from two strips ago
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!TRACK) break;
+        const int st = __builtin_amdgcn_readlane(res.cap_st, lq);  // lq: wave-uniform
+        if (st >= 0 || k == 0) break;
+        k = max(0, k - back);  // the path starts before this checkpoint
+        back <<= 1;
     }
     if (lane == lq) {
-        const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
-        a.p_best[o] = top.best;
-        a.p_second[o] = top.second;
-        a.p_end[o] = top.end;
-        a.p_st[o] = top.st;
+        if (TRACK) {
+            a.t_st[li] = res.cap_st;
+            a.t_end[li] = res.cap_end;
+        } else {
+            const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
+            a.p_best[o] = res.top.best;
+            a.p_second[o] = res.top.second;
+            a.p_end[o] = res.top.end;
+        }
     }
 }
 
 // instantiated in sdtw_inst_strips.hip
-extern template __global__ void sdtw_strip_kernel<false>(const StripArgs);
-extern template __global__ void sdtw_strip_kernel<true>(const StripArgs);
+extern template __global__ void sdtw_strip_kernel<false, false>(const StripArgs);
+extern template __global__ void sdtw_strip_kernel<true, false>(const StripArgs);
+extern template __global__ void sdtw_strip_kernel<false, true>(const StripArgs);
+extern template __global__ void sdtw_strip_kernel<true, true>(const StripArgs);
 
 struct StripFinalizeArgs {
     const int32_t *reads;  // [n_long]
     const float *p_best, *p_second;
-    const int32_t *p_end, *p_st;
+    const int32_t *p_end;
     const int32_t *job_contig;
     const int8_t *job_strand;
     const int32_t *ref_len, *ref_st_offset;
+    int32_t *w_job, *w_ws;  // mode 1 out: winners for pass 2
+    float *w_score;
+    const int32_t *t_st, *t_end;  // mode 2 in
     ResultRow *out;  // rows of the whole batch
     int32_t n_long, n_jobs;
+    int32_t mode;  // 1: after pass 1 -> scores, contig, strand, mapq + winners; 2: after pass 2 -> positions
 };
 
 #ifdef SFA_DEFINE_FINALIZE_KERNEL
 // merge the per-job top-2 of a long read in processing order (a later job wins ties, src/sigfish.c:577-583), then strand
-// flip, offset and mapq (src/sigfish.c:969-983) -- the single-pass branch of sdtw_finalize_kernel for the strip path
+// flip, offset and mapq (src/sigfish.c:969-983) -- sdtw_finalize_kernel for the strip path
 __global__ void __launch_bounds__(64) sdtw_strip_finalize_kernel(const StripFinalizeArgs a) {
     const int li = blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= a.n_long) return;
+    if (a.mode == 2) {
+        ResultRow r = a.out[a.reads[li]];
+        const int st = a.t_st[li], end = a.t_end[li];
+        if (r.rid < 0 || end < 0) return;
+        const int rl = a.ref_len[r.rid], off = a.ref_st_offset[r.rid];
+        r.pos_st = ((r.strand == '+') ? st : rl - end) + off;  // src/sigfish.c:971-975
+        r.pos_end = ((r.strand == '+') ? end : rl - st) + off;
+        a.out[a.reads[li]] = r;
+        return;
+    }
     float best = INFINITY, second = INFINITY;
-    int end = -1, st = -1, job = -1;
+    int ws = -1, job = -1;
     for (int j = 0; j < a.n_jobs; ++j) {
         const int64_t o = static_cast<int64_t>(li) * a.n_jobs + j;
         const float b = a.p_best[o], s2 = a.p_second[o];
@@ -265,8 +375,7 @@ __global__ void __launch_bounds__(64) sdtw_strip_finalize_kernel(const StripFina
         second = fminf(hi, lo2);
         if (take) {
             best = b;
-            end = a.p_end[o];
-            st = a.p_st[o];
+            ws = a.p_end[o];
             job = j;
         }
     }
@@ -280,16 +389,16 @@ __global__ void __launch_bounds__(64) sdtw_strip_finalize_kernel(const StripFina
     r.mapq = 0;
     r.valid = 1;
     r.pad = 0;
-    if (job >= 0 && end >= 0) {
-        const int rid = a.job_contig[job];
-        const int8_t d = a.job_strand[job];
-        const int rl = a.ref_len[rid], off = a.ref_st_offset[rid];
-        r.rid = rid;
-        r.strand = d;
+    if (job >= 0 && ws >= 0) {
+        r.rid = a.job_contig[job];
+        r.strand = a.job_strand[job];
         r.mapq = mapq_from_scores(best, second);
-        r.pos_st = ((d == '+') ? st : rl - end) + off;
-        r.pos_end = ((d == '+') ? end : rl - st) + off;
+    } else {
+        job = -1;
     }
+    a.w_job[li] = job;
+    a.w_ws[li] = ws;
+    a.w_score[li] = best;
     a.out[a.reads[li]] = r;
 }
 #endif

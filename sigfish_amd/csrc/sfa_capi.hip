@@ -140,7 +140,7 @@ struct sfa_ctx {
 
     // per-batch scratch
     DevBuf d_verify, d_segfail;
-    DevBuf d_bndc, d_bnds, d_long, d_lbest, d_lsecond, d_lend, d_lst;  // row strips (queries beyond SFA_MAX_QUERY, sdtw_strips.hpp)
+    DevBuf d_bndc, d_bnds, d_long, d_lbest, d_lsecond, d_lend, d_lwin, d_lck;  // row strips (queries beyond SFA_MAX_QUERY, sdtw_strips.hpp)
     PinBuf h_long;
     bool long_pending = false;
     int64_t seg_reruns = 0;  // batches walked again because a segment hand-over did not verify
@@ -219,36 +219,62 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
 int resolve_profile(sfa_ctx *c);
 int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out);
 
-// Reads of more than SFA_MAX_QUERY events: one wave per (read, job) sweeps the query in strips of 2048 rows, handing the
-// last row of a strip to the next one through HBM (sdtw_strips.hpp).  Runs after the wave kernels of the batch, on the same
-// stream, and overwrites the (invalid) rows they left for these reads.  Reads are taken in groups whose boundary rows fit
-// the checkpoint budget.
-int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const std::vector<int32_t> &reads, ResultRow *d_out) {
+// Reads of more than SFA_MAX_QUERY events: row strips (sdtw_strips.hpp).  Pass 1, one wave per (read, job), sweeps the
+// query in strips of 2048 rows, cost only, handing the last row of a strip to the next one through HBM; the strip finalize
+// names each read's winning (job, window, score); pass 2, one wave per read, sweeps the winning job again with start-column
+// tracking up to the end of the winning window.  Runs after the wave kernels of the batch, on the same stream, and
+// overwrites the (invalid) rows they left for these reads.  Reads are taken in groups whose boundary rows fit the
+// checkpoint budget.
+int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const std::vector<int32_t> &reads, int64_t max_qlen, ResultRow *d_out) {
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
     const size_t o_reads = 0, o_bnd = (sizeof(int32_t) * n_long + 7) & ~size_t(7);
-    const size_t stage_bytes = o_bnd + sizeof(int64_t) * (n_jobs + 1);
+    const size_t o_ck = o_bnd + sizeof(int64_t) * (n_jobs + 1);
+    const size_t stage_bytes = o_ck + sizeof(int64_t) * (n_jobs + 1);
     int rc;
     if ((rc = c->h_long.reserve(stage_bytes)) || (rc = c->d_long.reserve(stage_bytes))) return rc;
     char *hs = c->h_long.as<char>();
     memcpy(hs + o_reads, reads.data(), sizeof(int32_t) * n_long);
     int64_t *bnd_off = reinterpret_cast<int64_t *>(hs + o_bnd);
-    int64_t per = 0;
+    int64_t per = 0, row_max = 0;
     for (int32_t j = 0; j < n_jobs; ++j) {
+        const int64_t row = (static_cast<int64_t>(c->h_job_len[j]) + sfa::kBndPad + 3) & ~int64_t(3);
         bnd_off[j] = per;
-        per += (static_cast<int64_t>(c->h_job_len[j]) + sfa::kBndPad + 3) & ~int64_t(3);
+        per += row;
+        row_max = std::max(row_max, row);
     }
     bnd_off[n_jobs] = per;
-    const int64_t bytes_per_read = per * 2 * 8;  // two buffers of (cost, start column) per column
+    // checkpoints: every strip of every job, every T steps, 33 planes of 64 lanes; T = 512 unless that takes more than the
+    // budget for the whole set of long reads
+    const int32_t max_strips = static_cast<int32_t>((max_qlen + sfa::kStripRows - 1) / sfa::kStripRows);
+    int64_t *ck_off = reinterpret_cast<int64_t *>(hs + o_ck);
+    const int64_t rec_floats = (sfa::kStripR + 1) * 64;
+    int ck_shift = c->opt_ckpt_interval > 0 ? 2 : 9;
+    if (c->opt_ckpt_interval > 0)
+        while ((1ll << ck_shift) < c->opt_ckpt_interval) ++ck_shift;  // (the option's values are powers of two >= 4)
+    for (;; ++ck_shift) {
+        int64_t recs = 0;
+        for (int32_t j = 0; j < n_jobs; ++j) {
+            ck_off[j] = recs;
+            recs += static_cast<int64_t>(max_strips) * ((c->h_job_len[j] - 1) >> ck_shift);
+        }
+        ck_off[n_jobs] = recs;
+        if (c->opt_ckpt_interval > 0 || recs * rec_floats * 4 * n_long <= c->opt_ckpt_budget || ck_shift >= 14) break;
+    }
+    const int64_t ck_floats_per_read = ck_off[n_jobs] * rec_floats;
+    // two buffers: costs of every job's row (pass 1), start columns of one row (pass 2); + the checkpoints
+    const int64_t bytes_per_read = (per + row_max) * 2 * 4 + ck_floats_per_read * 4;
     const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(n_long, c->opt_ckpt_budget / std::max<int64_t>(bytes_per_read, 1))));
     const size_t n_part = static_cast<size_t>(n_long) * n_jobs;
-    if ((rc = c->d_bndc.reserve(sizeof(float) * 2 * per * group)) || (rc = c->d_bnds.reserve(sizeof(int32_t) * 2 * per * group)) ||
+    if ((rc = c->d_bndc.reserve(sizeof(float) * 2 * per * group)) || (rc = c->d_bnds.reserve(sizeof(int32_t) * 2 * row_max * group)) ||
         (rc = c->d_lbest.reserve(4 * n_part)) || (rc = c->d_lsecond.reserve(4 * n_part)) || (rc = c->d_lend.reserve(4 * n_part)) ||
-        (rc = c->d_lst.reserve(4 * n_part)))
+        (rc = c->d_lwin.reserve(4 * 5 * static_cast<size_t>(n_long))) ||
+        (rc = c->d_lck.reserve(sizeof(float) * std::max<int64_t>(ck_floats_per_read, 1) * group)))
         return rc;
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_long.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
     const char *ds = c->d_long.as<char>();
     const bool std_dtw = (c->flag & SFA_DTW) != 0;
+    int32_t *win = c->d_lwin.as<int32_t>();  // [5][n_long]: w_job, w_ws, w_score, t_st, t_end
     for (int32_t g0 = 0; g0 < n_long; g0 += group) {
         const int32_t gn = std::min(group, n_long - g0);
         sfa::StripArgs sa{};
@@ -261,34 +287,57 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.bnd_off = reinterpret_cast<const int64_t *>(ds + o_bnd);
         sa.bnd_cost = c->d_bndc.as<float>();
         sa.bnd_start = c->d_bnds.as<int32_t>();
+        sa.bnd_row_max = row_max;
         sa.p_best = c->d_lbest.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_second = c->d_lsecond.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_end = c->d_lend.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
-        sa.p_st = c->d_lst.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
+        sa.w_job = win + g0;
+        sa.w_ws = win + n_long + g0;
+        sa.w_score = reinterpret_cast<const float *>(win + 2 * static_cast<size_t>(n_long) + g0);
+        sa.t_st = win + 3 * static_cast<size_t>(n_long) + g0;
+        sa.t_end = win + 4 * static_cast<size_t>(n_long) + g0;
+        sa.ck = c->d_lck.as<float>();
+        sa.ck_off = reinterpret_cast<const int64_t *>(ds + o_ck);
+        sa.ck_shift = ck_shift;
+        sa.max_strips = max_strips;
+        sa.trace_margin = static_cast<int32_t>(c->opt_trace_margin);
         sa.n_long = gn;
         sa.n_jobs = n_jobs;
         sa.rev_query = ((c->flag & SFA_RNA) && !(c->flag & SFA_INV)) ? 1 : 0;
-        const int64_t tasks = static_cast<int64_t>(gn) * n_jobs;
-        const dim3 grid(static_cast<unsigned>((tasks + 3) / 4)), block(256);
-        if (std_dtw)
-            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<true>), grid, block, 0, st, sa);
-        else
-            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<false>), grid, block, 0, st, sa);
-        KERNEL_TRY();
         sfa::StripFinalizeArgs fa{};
         fa.reads = sa.reads;
         fa.p_best = sa.p_best;
         fa.p_second = sa.p_second;
         fa.p_end = sa.p_end;
-        fa.p_st = sa.p_st;
         fa.job_contig = c->d_job_contig.as<int32_t>();
         fa.job_strand = c->d_job_strand.as<int8_t>();
         fa.ref_len = c->d_ref_len.as<int32_t>();
         fa.ref_st_offset = c->d_ref_off.as<int32_t>();
+        fa.w_job = win + g0;
+        fa.w_ws = win + n_long + g0;
+        fa.w_score = reinterpret_cast<float *>(win + 2 * static_cast<size_t>(n_long) + g0);
+        fa.t_st = sa.t_st;
+        fa.t_end = sa.t_end;
         fa.out = d_out;
         fa.n_long = gn;
         fa.n_jobs = n_jobs;
-        hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, dim3((gn + 63) / 64), dim3(64), 0, st, fa);
+        const dim3 block(256), fgrid((gn + 63) / 64), fblock(64);
+        const dim3 grid1(static_cast<unsigned>((static_cast<int64_t>(gn) * n_jobs + 3) / 4)), grid2((gn + 3) / 4);
+        if (std_dtw)
+            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<true, false>), grid1, block, 0, st, sa);
+        else
+            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<false, false>), grid1, block, 0, st, sa);
+        KERNEL_TRY();
+        fa.mode = 1;
+        hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, fgrid, fblock, 0, st, fa);
+        KERNEL_TRY();
+        if (std_dtw)
+            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<true, true>), grid2, block, 0, st, sa);
+        else
+            hipLaunchKernelGGL((sfa::sdtw_strip_kernel<false, true>), grid2, block, 0, st, sa);
+        KERNEL_TRY();
+        fa.mode = 2;
+        hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, fgrid, fblock, 0, st, fa);
         KERNEL_TRY();
         c->prof.fill_launches++;
     }
@@ -341,11 +390,12 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.segment_warm_windows = c->opt_segment_warm;
     pp.allow_segments = !(c->flag & SFA_DTW) && !c->no_segments_once;
     std::vector<int32_t> long_reads;  // queries beyond the wave kernels' 2048 events: row strips, after the rest of the batch
-    int64_t long_events = 0;
+    int64_t long_events = 0, long_max = 0;
     for (int32_t i = 0; i < n; ++i)
         if (q_off[i + 1] - q_off[i] > sfa::kMaxQuery) {
             long_reads.push_back(i);
             long_events += q_off[i + 1] - q_off[i];
+            long_max = std::max<int64_t>(long_max, q_off[i + 1] - q_off[i]);
         }
     pp.skip_long = !long_reads.empty();
     sfa::BatchPlan plan;
@@ -494,7 +544,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     c->long_pending = !long_reads.empty();
     if (c->long_pending) {
         HIP_TRY(hipEventRecord(c->ev[5], st));
-        if ((rc = align_long(c, d_queries, da.q_off, long_reads, d_out))) return rc;
+        if ((rc = align_long(c, d_queries, da.q_off, long_reads, long_max, d_out))) return rc;
     }
     HIP_TRY(hipEventRecord(c->ev[4], st));
 
@@ -642,7 +692,7 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lst})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck})
         b->release();
     c->h_stage.release();
     c->h_out.release();

@@ -139,7 +139,7 @@ def test_long_queries(oracle, seed, mode, gpu_mode):
     assert_rows_equal(got, want)
 
 
-@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "auto"])
+@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto"])
 @pytest.mark.parametrize("seed", range(4))
 @pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
 def test_row_strips(oracle, seed, mode, gpu_mode):
@@ -185,6 +185,12 @@ def test_row_strips_ncov_and_groups(oracle):
         got = al.align_db(q, q_off)
         assert_rows_equal(got, want)
         assert (got["mapq"][[0, 2, 3]] > 0).all() and [chr(c) for c in got["strand"][[0, 2, 3]]] == ["+", "+", "-"]
+        for interval, margin in ((64, 0), (4, 3), (4096, -1), (512, 100)):  # pass 2 from any checkpoint spacing, incl. the back-off
+            al.set_option("ckpt_interval", interval)
+            al.set_option("trace_margin", margin)
+            assert al.align_db(q, q_off).tobytes() == got.tobytes()
+        al.set_option("ckpt_interval", 0)
+        al.set_option("trace_margin", -1)
         al.set_option("ckpt_budget_bytes", 1 << 20)  # less than one read's boundary rows: groups of one read
         assert al.align_db(q, q_off).tobytes() == got.tobytes()
         assert al.profile()["fill_launches"] == 1 + 3
