@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """fuzz_gpu.py -- randomised parity campaign of the HIP path against the oracle (run on an MI355X box):
 random reference shapes, ragged query lengths, DNA / RNA / std-DTW / invert, quantised values (exact ties),
-random checkpoint intervals, trace margins and lane shapes.  Usage: python tools/fuzz_gpu.py [iterations] [seed] [long]
+random checkpoint intervals, trace margins and lane shapes.  Usage: python tests/campaigns/fuzz_gpu.py [iterations] [seed] [long]
 (`long`: query lengths up to 9000 events, i.e. the row-strip path mixed with the wave kernels)"""
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sigfish_amd as S  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """parity_at_scale.py -- the HIP path against THE REFERENCE ITSELF (oracle/_ref/ref_bench: the reference's own align_db
 compiled from its sources) on thousands of synthetic reads per BASELINE workload shape.  Run on an MI355X box:
-    python tools/parity_at_scale.py [scale [workload:reads ...]]     (scale 1.0 ~ 5 minutes of host CPU on 16 cores)
+    python tests/campaigns/parity_at_scale.py [scale [workload:reads ...]]     (scale 1.0 ~ 5 minutes of host CPU on 16 cores)
 TEST TOOLING: it loads oracle/ and is not part of the product."""
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sigfish_amd as S  # noqa: E402
 from sigfish_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
