@@ -52,6 +52,9 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #ifndef SFA_FILL32_WAVES
 #define SFA_FILL32_WAVES 4  // the R = 32 shapes: 128 VGPRs (a handful of spills outside the loop); 81.5 -> 79.6 ms at q = 500
 #endif
+#ifndef SFA_XCD_MAP
+#define SFA_XCD_MAP 0  // blockIdx -> task: 0 = as dealt (round-robin over the XCDs), 1 = XCD-contiguous over the grid, 2 = XCD-contiguous per class
+#endif
 constexpr int kStepsPerLoad = SFA_STEPS_PER_LOAD;  // reference levels fetched per load (4 = one 16-byte load)
 constexpr int kMaxClasses = 6;     // query-length classes; base shapes (R, lanes) = (32,64) (32,32) (32,16) (16,16) (8,16) (4,16)
 
@@ -186,8 +189,9 @@ struct Top2 {
     }
 };
 
-// XCD-aware block remap (8 XCDs, blocks dealt round-robin): each XCD gets a contiguous range of logical
-// blocks, hence (tasks being chunk-major inside a class) mostly one reference chunk per XCD L2.  Speed only.
+// XCD-contiguous block remap (8 XCDs, blocks dealt round-robin): each XCD gets a contiguous range of logical
+// blocks, hence (tasks being chunk-major inside a class) mostly one reference chunk per XCD L2.  Only compiled in by the
+// A/B modes SFA_XCD_MAP = 1 / 2; the shipped mapping is the identity (see sdtw_fill_kernel).
 __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
     const int x = b & 7, i = b >> 3;
     const int q = nblk >> 3, rem = nblk & 7;
@@ -637,7 +641,24 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 template <int MAXR, bool TRACK, bool STD, bool SEG = false>
 __global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES))) sdtw_fill_kernel(const DpArgs a) {
     static_assert(!SEG || (!TRACK && !STD), "segments: cost-only subsequence DTW");
-    const int lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    // blockIdx -> task.  Blocks are dealt to the 8 XCDs round-robin, so with the identity every XCD sees every class and
+    // every chunk of the job list evenly -- what this kernel wants: the reference arrays (hundreds of KB to a few MB) stay
+    // resident in every XCD's L2 anyway, whereas the classes differ in speed.  Measured (A/B builds, fill ms): identity
+    // 75.9 / contiguous per class 76.2 / contiguous over the grid 77.7 on the headline workload, 269 / 275 / 278 on RNA004
+    // --dtw-std, 2 438 / 2 438 / 2 474 on the 1 Mb reference.  (One contiguous range per XCD over the whole grid hands all
+    // the short, fast classes at the end of the task list to the last XCD, which then idles while the other seven finish.)
+    int lblk = blockIdx.x;
+#if SFA_XCD_MAP == 1
+    lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
+#elif SFA_XCD_MAP == 2
+    {
+        int cb = 0;
+        while (cb + 1 < a.n_cls && static_cast<int>(blockIdx.x) >= (a.cls[cb + 1].task_base >> 2)) ++cb;
+        const int lo = a.cls[cb].task_base >> 2;
+        const int hi = (cb + 1 < a.n_cls) ? (a.cls[cb + 1].task_base >> 2) : static_cast<int>(gridDim.x);
+        lblk = lo + xcd_contiguous_block(blockIdx.x - lo, hi - lo);
+    }
+#endif
     const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
     if (task >= a.n_tasks) return;  // wave-uniform
     int ci = 0;
