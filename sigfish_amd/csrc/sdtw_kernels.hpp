@@ -52,6 +52,9 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #ifndef SFA_FILL32_WAVES
 #define SFA_FILL32_WAVES 4  // the R = 32 shapes: 128 VGPRs (a handful of spills outside the loop); 81.5 -> 79.6 ms at q = 500
 #endif
+#ifndef SFA_TRACE_WAVES
+#define SFA_TRACE_WAVES 4  // waves per SIMD pass 2 (R <= 16) is register-budgeted for: 128 VGPRs; 3.49 -> 3.28 ms per 100 k reads against 144 VGPRs / 3 waves
+#endif
 #ifndef SFA_XCD_MAP
 #define SFA_XCD_MAP 0  // blockIdx -> task: 0 = as dealt (round-robin over the XCDs), 1 = XCD-contiguous over the grid, 2 = XCD-contiguous per class
 #endif
@@ -844,7 +847,7 @@ struct FinalizeArgs {
 };
 
 template <int MAXR, bool STD>
-__global__ void __launch_bounds__(256) sdtw_trace_kernel(const DpArgs a, int32_t *out_st) {
+__global__ void __launch_bounds__(256, MAXR <= 16 ? SFA_TRACE_WAVES : 1) sdtw_trace_kernel(const DpArgs a, int32_t *out_st) {
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (task >= a.n_tasks) return;
     int ci = 0;
