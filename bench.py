@@ -159,7 +159,7 @@ def main():
     # HBM bytes per fill launch from the committed PMC passes of this build (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     # KB -> bytes; MI355X_MICROARCH.md section HBM).  Only quoted for the configuration that was profiled.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_v14_pmc_summary.csv")
+    pmc = os.path.join(ROOT, "profiles", "r01_v15_pmc_summary.csv")
     if os.path.exists(pmc) and args.workload == "ncov_r9_dna_q250" and n == 100_000 and not args.opt:
         vals = {}
         for line in open(pmc).read().splitlines()[1:]:
@@ -168,7 +168,7 @@ def main():
                 vals[counter] = float(mean)
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            traffic_src = "profiles/r01_v14_pmc_summary.csv (separate rocprofv3 --pmc passes of this build, same workload)"
+            traffic_src = "profiles/r01_v15_pmc_summary.csv (separate rocprofv3 --pmc passes of this build, same workload)"
     out = {
         "metric": ("reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)" if args.workload == "ncov_r9_dna_q250"
                    else f"reads/s (sDTW alignment stage: {args.workload})"),
