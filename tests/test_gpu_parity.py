@@ -196,6 +196,26 @@ def test_row_strips_ncov_and_groups(oracle):
         assert al.profile()["fill_launches"] == 1 + 3
 
 
+def test_row_strips_extreme_lengths(oracle):
+    """Queries of 12 345 and 20 000 events and one as long as the reference itself (29 898 events: 15 strips, a single
+    window per strand) next to ordinary ones."""
+    ref, flag, _, _, _ = synth.workload("ncov_r9_dna_q250", n_reads=8, seed=0)
+    rng = np.random.default_rng(5)
+    qlens = np.array([20000, 12345, 2049, 250, 29898])
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = np.empty(int(q_off[-1]), np.float32)
+    for i, l in enumerate(qlens):
+        src = ref.forward[0] if i % 2 == 0 else ref.reverse[0]
+        st = int(rng.integers(0, len(src) - l + 1))
+        seg = src[st:st + l] + rng.normal(scale=0.3, size=l).astype(np.float32)
+        q[q_off[i]:q_off[i + 1]] = ((seg - seg.mean()) / seg.std()).astype(np.float32)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=5)
+    with S.Aligner(ref, flag) as al:
+        got = al.align_db(q, q_off)
+    assert_rows_equal(got, want)
+    assert [chr(c) for c in got["strand"]] == ["+", "-", "+", "-", "+"] and (got["mapq"] == 60).all()
+
+
 def test_long_queries_ncov(oracle):
     """q = 1000 and 2000 against the nCoV reference (both strands), default checkpointing."""
     ref, flag, q250, off250, meta = synth.workload("ncov_r9_dna_q250", n_reads=8, seed=11)
