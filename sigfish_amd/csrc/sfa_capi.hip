@@ -151,6 +151,7 @@ struct sfa_ctx {
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
         e_qoff, e_b0, e_b1, e_b2, e_flag, e_qev, e_pflag;
 
+    sfa::BatchPlan plan;  // plan of the batch being submitted (scratch included)
     sfa_profile_t prof{};
     bool prof_pending = false;
     bool no_segments_once = false;  // re-run of a batch whose segment hand-overs did not verify
@@ -398,7 +399,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
             long_max = std::max<int64_t>(long_max, q_off[i + 1] - q_off[i]);
         }
     pp.skip_long = !long_reads.empty();
-    sfa::BatchPlan plan;
+    sfa::BatchPlan &plan = c->plan;  // kept with the context: its vectors are reused by every batch
     std::string perr;
     if (int rc = sfa::plan_batch(q_off, n, c->h_job_len, c->total_cols, pp, &plan, &perr)) return fail(rc, "%s", perr.c_str());
     if (!c->in_slice && !plan.single_pass && c->opt_ckpt_interval == 0 && plan.ck_shift > 9 && n >= 2 * c->opt_min_slice_reads) {

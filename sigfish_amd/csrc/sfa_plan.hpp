@@ -80,6 +80,18 @@ struct BatchPlan {
     std::vector<int32_t> chunk_begin;   // [n_chunks+1]
     std::vector<int32_t> job_ck_off;    // [n_jobs+1]
     std::vector<PlanClass> classes;
+    // scratch of plan_batch(), kept with the plan: a caller that reuses one BatchPlan for every batch (the library does)
+    // pays no allocation in the steady state -- the vectors of a 100 000-read plan are 400 KB each, i.e. one mmap / page-fault
+    // round per vector and call otherwise (1.35 -> 0.75 ms per plan)
+    std::vector<int32_t> s_qlen, s_count, s_quad_start, s_fill_pos;
+    std::vector<int8_t> s_per_shift;
+    void reset() {  // scalars back to their defaults; vectors keep their capacity
+        n_quads = 0; n_chunks = 1; max_R = 4; max_lanes = 16; widening = 1; ck_shift = 0; trace_margin = 0;
+        n_seg = 1; warm_windows = 4;
+        single_pass = false;
+        ck_floats = 0; query_events = 0;
+        classes.clear();
+    }
 };
 
 // Split the job list into n_chunks contiguous, non-empty ranges of roughly equal reference columns.
@@ -100,10 +112,12 @@ inline void split_jobs(const std::vector<int32_t> &job_len, int64_t total_cols, 
 inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t> &job_len, int64_t total_cols,
                       const PlanParams &pp, BatchPlan *out, std::string *err) {
     BatchPlan &p = *out;
-    p = BatchPlan();
+    p.reset();
     p.single_pass = pp.single_pass;
     const int32_t n_jobs = static_cast<int32_t>(job_len.size());
-    std::vector<int32_t> qlen(n, 0);
+    std::vector<int32_t> &qlen = p.s_qlen, &count = p.s_count, &quad_start = p.s_quad_start, &fill_pos = p.s_fill_pos;
+    qlen.assign(n, 0);
+    count.assign(kMaxQuery + 2, 0);
     int maxq = 0;
     for (int32_t i = 0; i < n; ++i) {
         const int64_t l = q_off[i + 1] - q_off[i];
@@ -117,14 +131,13 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
             return -4;  // SFA_ERANGE
         }
         qlen[i] = static_cast<int32_t>(l);
+        count[l]++;
         maxq = std::max(maxq, qlen[i]);
         p.query_events += l;
     }
-    std::vector<int32_t> count(maxq + 2, 0);
-    for (int32_t i = 0; i < n; ++i) count[qlen[i]]++;
     // classes in task order (long first); inside a class by descending length.  layout(w) fills the plan for lane
     // widening w and returns the number of quads (waves' worth of reads).
-    std::vector<int32_t> quad_start(maxq + 2, -1);
+    quad_start.assign(maxq + 2, -1);
     auto layout = [&](int w) {
         p.classes.clear();
         int32_t n_quads = 0;
@@ -176,13 +189,20 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     p.order.assign(4 * static_cast<size_t>(std::max(n_quads, 1)), -1);
     p.quad_qlen.assign(std::max(n_quads, 1), 1);
     p.slot_of_read.assign(n, -1);
-    std::vector<int32_t> fill_pos(maxq + 2, 0);
+    fill_pos.assign(maxq + 2, 0);
+    std::vector<int8_t> &per_shift = p.s_per_shift;
+    per_shift.assign(maxq + 2, 0);  // log2(reads per wave) of every query length that occurs (4, 2 or 1 reads)
+    for (int l = 1; l <= maxq; ++l)
+        if (count[l]) {
+            const int per = 64 / widened(class_for(l), w).lanes;
+            per_shift[l] = per == 4 ? 2 : (per == 2 ? 1 : 0);
+        }
     for (int32_t i = 0; i < n; ++i) {
         const int l = qlen[i];
         if (l == 0) continue;
         const int32_t k = fill_pos[l]++;
-        const int per = 64 / widened(class_for(l), w).lanes;
-        const int32_t sl = (quad_start[l] + k / per) * 4 + (k % per);  // a wave always has four slots; wide shapes use 2 / 1
+        const int sh = per_shift[l];
+        const int32_t sl = (quad_start[l] + (k >> sh)) * 4 + (k & ((1 << sh) - 1));  // a wave always has four slots; wide shapes use 2 / 1
         p.order[sl] = i;
         p.slot_of_read[i] = sl;
     }
