@@ -199,6 +199,35 @@ def random_goldens():
     print("random goldens written")
 
 
+def random_goldens_long():
+    """Six long synthetic DNA signals (30-50 k samples, 3-5 k events) through the reference's batch loop with -q beyond 2048
+    events: end-to-end known answers for the row-strip path on both strands."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import write_blow5  # noqa: E402
+    rd = os.path.join(GOLD, "random")
+    os.makedirs(rd, exist_ok=True)
+    rng = np.random.default_rng(20241005)
+
+    def signal(n):
+        dwell = rng.integers(4, 16, size=n // 4 + 2)
+        levels = rng.normal(rng.uniform(400, 600), rng.uniform(40, 90), size=len(dwell))
+        x = np.repeat(levels, dwell)[:n] + rng.normal(0, rng.uniform(1, 6), size=n)
+        return np.clip(np.round(x), -2000, 4000).astype(np.int16)
+
+    reads = [(f"dnalong{i:02d}", 8192.0, float(rng.integers(-20, 40)), float(rng.uniform(900, 1500)), 4000.0,
+              signal(int(rng.integers(30000, 50000)))) for i in range(6)]
+    blow5 = os.path.join(rd, "rnd_dnalong.blow5")
+    write_blow5(blow5, reads, attrs=(("experiment_type", "genomic_dna"), ("sequencing_kit", "unknown")), compress=True)
+    for name, args in (("rnd_dnalong_q3000", ["-q", "3000"]), ("rnd_dnalong_q2500_sam", ["-q", "2500", "--sam"])):
+        out = subprocess.run([O.REF_DRIVER, "--model", os.path.join(GOLD, "models", "syn6.f32"), "--kmer", "6", *args,
+                              os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), blow5], check=True, capture_output=True).stdout
+        with open(os.path.join(rd, name + ".out"), "wb") as f:
+            f.write(out)
+        with open(os.path.join(rd, name + ".args"), "w") as f:
+            f.write("\n".join(["6", "nCoV-2019.reference.fasta", os.path.basename(blow5)] + args))
+    print("long random goldens written")
+
+
 def main():
     O.build()
     assert os.path.exists(O.REF_DRIVER), "oracle/_ref missing (needs /root/reference)"
@@ -212,6 +241,9 @@ def main():
     synth_levels(6, 1, 90, 12).tofile(os.path.join(GOLD, "models", "syn6.f32"))
     synth_levels(5, 2, 100, 14).tofile(os.path.join(GOLD, "models", "syn5.f32"))
     only = sys.argv[1:]  # case names: regenerate just these (the other fixtures are left as they are)
+    if only == ["random_long"]:
+        random_goldens_long()
+        return
     for c in CASES:
         if not only or c[0] in only:
             run_case(*c)
@@ -220,6 +252,7 @@ def main():
     kernel_vectors()
     eval_goldens()
     random_goldens()
+    random_goldens_long()
 
 
 if __name__ == "__main__":
