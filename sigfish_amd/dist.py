@@ -60,21 +60,41 @@ def broadcast_ref(ref, flag, device=None, src=0):
     return api.RefModel(names[0], seql, lens, offs, fw, rv), flag
 
 
+_PINNED = {}  # bytes -> page-locked host tensor, reused by every gather of that size
+
+
+def _to_host(t):
+    """Device tensor -> host numpy view of its bytes, through a cached page-locked buffer (one DMA, no further copies)."""
+    if t.device.type == "cpu":
+        return t.numpy()
+    buf = _PINNED.get(t.numel())
+    if buf is None:
+        buf = _PINNED[t.numel()] = torch.empty(t.numel(), dtype=torch.uint8, pin_memory=True)
+    buf.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return buf.numpy()
+
+
 def gather_rows(rows, counts, device=None, dst=0):
     """rows: this rank's result rows as a uint8 tensor [n_local*24] (GPU or CPU).  counts: reads per rank.
-    Returns on `dst` a structured array with all rows in rank (= read) order, None elsewhere."""
+    Returns on `dst` a structured array with all rows in rank (= read) order, None elsewhere.  (The array may be a view
+    of a reused page-locked buffer: copy it if it has to outlive the next gather of the same size.)"""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
-        return np.frombuffer(rows.cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE)
+        return _to_host(rows).view(api.RESULT_DTYPE)
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = rows.device
     item = api.RESULT_DTYPE.itemsize
     width = max(counts) * item
-    send = torch.zeros(width, dtype=torch.uint8, device=dev)
-    send[:rows.numel()] = rows
-    recv = [torch.zeros(width, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+    send = rows
+    if rows.numel() != width:  # ragged shards: pad to the widest
+        send = torch.empty(width, dtype=torch.uint8, device=dev)
+        send[:rows.numel()] = rows
+    big = torch.empty(world * width, dtype=torch.uint8, device=dev) if rank == dst else None
+    recv = list(big.split(width)) if rank == dst else None  # views: the shards land next to each other
     dist.gather(send, recv, dst=dst)
     if rank != dst:
         return None
-    parts = [np.frombuffer(recv[r][:counts[r] * item].cpu().numpy().tobytes(), dtype=api.RESULT_DTYPE)
-             for r in range(world)]
-    return np.concatenate(parts)
+    host = _to_host(big)
+    if all(c * item == width for c in counts):
+        return host.view(api.RESULT_DTYPE)  # equal shards: already in read order, no copy
+    return np.concatenate([host[r * width:r * width + counts[r] * item] for r in range(world)]).view(api.RESULT_DTYPE)
