@@ -170,11 +170,14 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         w = static_cast<int>(pp.lane_widening);
         if (w != 1) n_quads = layout(w);
     } else {
-        // measured (tools/small_batches.sh, nCoV, q = 250, profiles/r01_logs): up to ~5 waves per SIMD a batch is
-        // latency-bound and the 4-rows-per-lane shapes win (512 reads: 4.2 -> 2.0 ms, 4 096: 6.4 -> 5.2, 8 192: 10.2 ->
-        // 9.7); from ~6 on the 16-lane shapes do (3 % at 16 Ki reads, 14 % at 32 Ki); x2 is never the best
-        if (static_cast<int64_t>(n_quads) * chunks_for(n_quads) < pp.widen_below * pp.n_sims) {
-            w = 4;
+        // measured (nCoV, q = 250, profiles/r01_logs/small_batches_widening_crossover_head.log; t = wave-tasks per SIMD with the
+        // 16-lane shapes = reads / 2048 here): the 4-rows-per-lane shapes win up to t ~ 0.9 (1 024 reads: 4.2 / 2.8 / 1.7 ms at
+        // x1 / x2 / x4), the 8-rows shapes from there to t ~ 3.9 (4 096 reads: 6.5 / 5.1 / 5.5 ms; 6 144: 8.5 / 7.1 / 7.7), the
+        // 16-lane shapes from t = 4 on (8 192 reads: 8.8 / 9.1 / 9.9 ms).  widen_below = 5 is the default; a caller with several
+        // batches in flight per device lowers it and all three ranges shrink with it.
+        const int64_t tasks1 = static_cast<int64_t>(n_quads) * chunks_for(n_quads);
+        if (tasks1 * 5 < pp.widen_below * pp.n_sims * 4) {                         // t < 0.8 widen_below
+            w = (tasks1 * 50 < pp.widen_below * pp.n_sims * 9) ? 4 : 2;            // t < 0.18 widen_below
             n_quads = layout(w);
         }
     }

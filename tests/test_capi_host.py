@@ -163,13 +163,17 @@ def test_plan_batch_lane_widening():
     for s, per250 in ((s1, 4), (s2, 2), (s4, 1)):
         assert len(np.unique(s)) == len(s)
         assert ((s[:10] & 3) < per250).all()
-    # auto: a small batch widens fully, a big one does not (1024 SIMDs assumed, fewer than 5 waves per SIMD widens)
+    # auto (1024 SIMDs assumed; t = wave-tasks per SIMD with the 16-lane shapes = reads / 2048 on two strands): x4 below
+    # t = 0.9, x2 below t = 4, the 16-lane shapes from there on
     assert plan_batch(q_off, [29898, 29898])[0]["lane_widening"] == 4
     big = np.arange(0, 250 * 20001, 250, dtype=np.int64)
     assert plan_batch(big, [29898, 29898])[0]["lane_widening"] == 1
-    mid = np.arange(0, 250 * 10241, 250, dtype=np.int64)     # 2560 waves x 2 chunks = 5 per SIMD: stays
+    mid = np.arange(0, 250 * 10241, 250, dtype=np.int64)
     assert plan_batch(mid, [29898, 29898])[0]["lane_widening"] == 1
-    assert plan_batch(mid[:8193], [29898, 29898])[0]["lane_widening"] == 4
+    assert plan_batch(mid[:8193], [29898, 29898])[0]["lane_widening"] == 1   # 8 192 reads: t = 4
+    assert plan_batch(mid[:8001], [29898, 29898])[0]["lane_widening"] == 2
+    assert plan_batch(mid[:2049], [29898, 29898])[0]["lane_widening"] == 2   # 2 048 reads: t = 1
+    assert plan_batch(mid[:1801], [29898, 29898])[0]["lane_widening"] == 4
     with pytest.raises(S.SfaError):
         plan_batch(q_off, [100], lane_widening=3)
 
