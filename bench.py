@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MI355X sDTW alignment stage on the BASELINE.json headline configuration.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, driver's form)
+
+One process per GPU.  Without WORLD_SIZE/RANK in the environment `--gpus N` (N > 1) makes this process a supervisor
+that starts N fresh child ranks (sigfish_amd/launch.py) BEFORE anything touches the GPU and exits with their worst
+code; a mismatch between --gpus and the ranks that actually exist is an error, never a silently smaller run.
 
 Workload (config.workload = "ncov_r9_dna_q250", BASELINE.json configs[2]): synthetic R9 DNA reads (250 events,
 5 % shorter) against the 29 903 b nCoV-2019 reference, both strands, -q 250.  A "step" is one pass of the hot
@@ -63,6 +67,14 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="sfa_set_option key=value (tuning experiments)")
     args = ap.parse_args()
 
+    # ---- ranks: the launcher's, or our own (never a re-exec of a process that has touched the GPU) ----------------
+    from sigfish_amd import launch  # pure Python, loads nothing native
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launch.launched_by_a_launcher() and args.gpus > 1:
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    launch_test = os.environ.get("SFA_BENCH_LAUNCH_TEST") == "1"  # tests/test_bench_launch.py: rendezvous only, gloo, no GPU
+
     import torch
     import torch.distributed as dist
 
@@ -73,8 +85,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) exist (WORLD_SIZE={os.environ.get('WORLD_SIZE')}): refusing to "
+                         f"report a {world}-rank number under an {args.gpus}-GPU label")
+    if launch_test:  # the launch path on CPU: N ranks rendezvous over gloo and count themselves
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_test": True, "n_gpus": int(t.item()), "world": dist.get_world_size()}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if torch.cuda.device_count() < (local_rank + 1 if world > 1 else 1):  # (device_count does not initialise the GPU here)
+        raise SystemExit(f"rank {rank}: local GPU {local_rank} does not exist ({torch.cuda.device_count()} visible)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -175,6 +199,7 @@ def main():
         "value": round(value, 1),
         "unit": "reads/s",
         "n_gpus": world,
+        "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
