@@ -93,6 +93,13 @@ typedef struct {
     int64_t n_chunks;      /* pieces the (contig,strand) list was cut into */
     int64_t n_segments;    /* column segments per (contig,strand) (1: off; small batches use several, verified) */
     int64_t segment_reruns; /* batches of this context walked again because a segment hand-over did not verify */
+    /* sfa_align_raw only (0 otherwise): the stages in front of the alignment, the reference's "Events time" and
+     * "Normalise time" (src/sigfish.c:1026-1035) as device time */
+    double events_ms;      /* pA conversion, prefix sums, t-statistics, peak picking, event statistics */
+    double normalise_ms;   /* query windows: z-normalisation + packing (the window choice itself is host arithmetic) */
+    /* reads of the batch whose query holds a NaN or +-inf event.  The reference aborts on such a read (assert in update_aln,
+     * src/sigfish.c:611); here they are skipped: their rows come back with valid = 0. */
+    int64_t non_finite_reads;
 } sfa_profile_t;
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */
@@ -113,6 +120,20 @@ typedef struct {
 /* Create a context on HIP device `device`, copy the reference event arrays into HBM.
  * flag: SFA_* bits.  The arrays behind `ref` may be freed after the call returns. */
 int sfa_init(sfa_ctx_t **ctx, const sfa_ref_t *ref, uint32_t flag, int device);
+
+/* The same context over SEVERAL devices of one node (multi-GPU behind this ABI): reads shard
+ * embarrassingly, so the context owns one ordinary context per entry of devices[] and every align call below cuts its
+ * batch into contiguous read ranges [r*n/G, (r+1)*n/G), runs them side by side (one host thread per device inside the
+ * call) and writes the rows into the caller's array in input order -- no collective on the data path.  The reference
+ * event model crosses PCIe once, to devices[0], and travels device to device from there (hipMemcpyPeer, xGMI between the
+ * GPUs of a node): the "broadcast, root 0" of the multi-GPU design.  A device may be listed more than once (two shards on
+ * one GPU).  Works with sfa_align_batch, sfa_submit_batch / sfa_wait_batch, sfa_align_events, sfa_align_raw(_ex),
+ * sfa_set_option (applies to every shard), sfa_sync, sfa_get_profile (slowest shard's times, summed counts), sfa_destroy;
+ * sfa_align_batch_device and sfa_stream need a single-device context (device memory and streams belong to one GPU). */
+int sfa_init_devices(sfa_ctx_t **ctx, const sfa_ref_t *ref, uint32_t flag, const int *devices, int n_devices);
+
+/* Shards behind a context: 1 for sfa_init, n_devices for sfa_init_devices. */
+int sfa_n_devices(sfa_ctx_t *ctx);
 
 /* Align a batch.  queries: concatenated, already z-normalised event means in EVENT order (the library applies
  * the RNA reversal of src/sigfish.c:860-866 itself); q_off[n_reads+1] offsets into queries; a read with
@@ -245,6 +266,16 @@ int sfa_select_query(sfa_event_t *events, int64_t n_events, const int16_t *raw, 
 int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname,
                 const sfa_event_t *events, int64_t qstart, int64_t qend, const float *ref_array, int32_t ref_len,
                 int32_t ref_st_offset, uint32_t flag);
+
+/* aln_t.r2qevent_map for a result row (path_to_map, src/sigfish.c:530-571, as update_aln stores it at 610-613): what the
+ * reference's own sam_str / r2qevent_map_to_ss (src/sigfish.c:663-794) consume.  The winner's warp path is rebuilt on the
+ * host from the band between its start and end columns, exactly as for sfa_sam_row; arguments as there.
+ * pairs[2*i], pairs[2*i+1] = start, stop (query event indices relative to qstart, in DP order) for reference column
+ * pos_st + i -- the memory layout of index_pair_t[] (src/sigfish.h:141-144), so a C host may pass its own array.
+ * Returns r2qevent_size = pos_end - pos_st + 1 (also when pairs is NULL: size query), SFA_ERANGE if cap_pairs (in pairs)
+ * is smaller than that, SFA_EINVAL for an unaligned row. */
+int32_t sfa_r2qevent_map(const sfa_result_t *r, const sfa_event_t *events, int64_t qstart, int64_t qend, const float *ref_array,
+                         int32_t ref_len, int32_t ref_st_offset, uint32_t flag, int32_t *pairs, int32_t cap_pairs);
 
 /* read_model (src/model.c:38-131): text k-mer model -> level_mean[4^k] (levels must hold 262144 floats). */
 int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k);

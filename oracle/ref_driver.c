@@ -21,6 +21,9 @@ refsynth_t *gen_ref(const char *genome, model_t *pore_model, uint32_t kmer_size,
 void free_ref(refsynth_t *ref);
 void free_db(db_t *db);
 int eval_main(int argc, char *argv[]); /* src/eval.c:380 */
+#ifdef HAVE_ACC /* `make ref-acc`: the reference built with acc=1 + oracle/ref_acc.patch; the teardown slot of free_core() */
+void sigfish_acc_free(void);
+#endif
 
 static void wr(FILE *f, const void *p, size_t n) { fwrite(p, 1, n, f); }
 
@@ -142,6 +145,9 @@ int main(int argc, char **argv) {
         fprintf(stderr, "parse %.4f events %.4f normalise %.4f dtw %.4f\n", core->parse_time, core->event_time,
                 core->normalise_time, core->dtw_time);
     free_db(db);
+#ifdef HAVE_ACC
+    if (core->opt.flag & SIGFISH_ACC) sigfish_acc_free(); /* free_core(), src/sigfish.c:221-225 (not callable here: model.c is absent) */
+#endif
     free_ref(core->ref);
     slow5_close(core->sf);
     free(core->model);

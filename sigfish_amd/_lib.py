@@ -25,7 +25,8 @@ class SfaProfile(C.Structure):
     _fields_ = [("fill_ms", C.c_double), ("trace_ms", C.c_double), ("finalize_ms", C.c_double),
                 ("total_ms", C.c_double), ("cells", C.c_int64), ("fill_launches", C.c_int64),
                 ("ckpt_interval", C.c_int64), ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64),
-                ("n_chunks", C.c_int64), ("n_segments", C.c_int64), ("segment_reruns", C.c_int64)]
+                ("n_chunks", C.c_int64), ("n_segments", C.c_int64), ("segment_reruns", C.c_int64),
+                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64)]
 
 
 class SfaPlanInfo(C.Structure):
@@ -44,10 +45,10 @@ class SfaEvent(C.Structure):
     _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float)]
 
 
-# every symbol include/sigfish_amd.h declares (checked by tests/test_capi_symbols.py)
-SYMBOLS = ["sfa_init", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
+# every symbol include/sigfish_amd.h declares (checked by tests/test_capi_host.py::test_library_exports_every_declared_symbol)
+SYMBOLS = ["sfa_init", "sfa_init_devices", "sfa_n_devices", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
-           "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
+           "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_r2qevent_map", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close", "sfa_inflate_zlib", "sfa_device_memory"]
 
 _lib = None
@@ -64,6 +65,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.sfa_init.argtypes = [C.POINTER(vp), C.POINTER(SfaRef), C.c_uint32, C.c_int]
+    L.sfa_init_devices.argtypes = [C.POINTER(vp), C.POINTER(SfaRef), C.c_uint32, C.POINTER(C.c_int), C.c_int]
+    L.sfa_n_devices.argtypes = [vp]
     L.sfa_align_batch.argtypes = [vp, f32p, i64p, C.c_int32, vp]
     L.sfa_submit_batch.argtypes = [vp, f32p, i64p, C.c_int32]
     L.sfa_wait_batch.argtypes = [vp, vp, C.c_int32]
@@ -95,6 +98,9 @@ def load():
     i16p = C.POINTER(C.c_int16)
     L.sfa_sam_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(SfaResult), C.c_char_p, C.c_char_p, C.POINTER(SfaEvent),
                               C.c_int64, C.c_int64, f32p, C.c_int32, C.c_int32, C.c_uint32]
+    L.sfa_r2qevent_map.argtypes = [C.POINTER(SfaResult), C.POINTER(SfaEvent), C.c_int64, C.c_int64, f32p, C.c_int32, C.c_int32,
+                                   C.c_uint32, i32p, C.c_int32]
+    L.sfa_r2qevent_map.restype = C.c_int32
     L.sfa_detect_events.argtypes = [i16p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(SfaEvent),
                                     C.c_int64]
     L.sfa_detect_events.restype = C.c_int64

@@ -126,13 +126,22 @@ class RefModel:
 class Aligner:
     """The accelerator context: reference arrays resident in HBM, batches aligned by the gfx950 kernels."""
 
-    def __init__(self, ref: RefModel, flag=0, device=0):
+    def __init__(self, ref: RefModel, flag=0, device=0, devices=None):
+        """device: one GPU (sfa_init).  devices: a list of GPUs (sfa_init_devices) -- every batch is then sharded over them
+        in contiguous read ranges and comes back in input order; a GPU may be listed more than once."""
         self._L = _lib.load()
         self._h = C.c_void_p()
         self.ref, self.flag, self.device = ref, int(flag), int(device)
         cref, keep = ref._as_c()
-        _check(self._L.sfa_init(C.byref(self._h), C.byref(cref), self.flag, self.device), "sfa_init")
+        if devices is None:
+            _check(self._L.sfa_init(C.byref(self._h), C.byref(cref), self.flag, self.device), "sfa_init")
+        else:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(self._L.sfa_init_devices(C.byref(self._h), C.byref(cref), self.flag, devs, len(devices)), "sfa_init_devices")
         del keep
+
+    def n_devices(self):
+        return int(self._L.sfa_n_devices(self._h))
 
     def close(self):
         if self._h:
@@ -350,6 +359,25 @@ def read_kmer_model(path):
     _check(_lib.load().sfa_read_kmer_model(str(path).encode(), lv.ctypes.data_as(_lib.f32p), C.byref(k)),
            "sfa_read_kmer_model")
     return lv[:4 ** k.value].copy(), k.value
+
+
+def r2qevent_map(res, events, qstart, qend, ref_array, ref_st_offset, flag):
+    """aln_t.r2qevent_map (path_to_map, src/sigfish.c:530-571) for one result row: int32 [r2qevent_size, 2] = start, stop."""
+    r = _lib.SfaResult(int(res["rid"]), int(res["pos_st"]), int(res["pos_end"]), float(res["score"]),
+                       float(res["score2"]), int(res["strand"]), int(res["mapq"]), int(res["valid"]), 0)
+    y = _f32(ref_array)
+    L = _lib.load()
+    evp = C.cast(events.ctypes.data, C.POINTER(_lib.SfaEvent))
+    need = L.sfa_r2qevent_map(C.byref(r), evp, int(qstart), int(qend), y.ctypes.data_as(_lib.f32p), len(y), int(ref_st_offset),
+                              int(flag), None, 0)
+    if need < 0:
+        raise SfaError(f"sfa_r2qevent_map failed ({need})")
+    out = np.zeros((need, 2), np.int32)
+    n = L.sfa_r2qevent_map(C.byref(r), evp, int(qstart), int(qend), y.ctypes.data_as(_lib.f32p), len(y), int(ref_st_offset),
+                           int(flag), out.ctypes.data_as(_lib.i32p), need)
+    if n != need:
+        raise SfaError(f"sfa_r2qevent_map failed ({n})")
+    return out
 
 
 def sam_row(res, read_id, rname, events, qstart, qend, ref_array, ref_st_offset, flag):

@@ -13,6 +13,7 @@
 #include <functional>
 #include <future>
 #include <mutex>
+#include <stdexcept>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -58,9 +59,20 @@ double cputime() {
     return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
 }
 
-[[noreturn]] void die(const std::string &msg) {
-    fprintf(stderr, "[sigfish-amd] ERROR: %s\n", msg.c_str());
-    exit(EXIT_FAILURE);
+// Errors travel as exceptions: die() may be called on a helper thread (the GPU stage or the output stage of a batch,
+// both std::async) while the main thread, the worker pool and another GPU stage are still running.  exit() from there
+// would run static destructors and the HIP runtime's teardown under live kernels and threads; instead the exception
+// crosses the future, the stack unwinds (futures of std::async wait for their thread, the pool joins its workers) and
+// dtw_main() prints the message and returns the failure status from the main thread.
+struct Fatal : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+[[noreturn]] void die(const std::string &msg) { throw Fatal(msg); }
+
+bool yes_or_no(const char *arg, const char *what) {  // yes_or_no(), src/dtw_main.c:92-113
+    if (!strcmp(arg, "yes") || !strcmp(arg, "y")) return true;
+    if (!strcmp(arg, "no") || !strcmp(arg, "n")) return false;
+    die(std::string("option '--") + what + "' only accepts 'yes' or 'no'.");
 }
 
 int64_t parse_num(const char *s) {  // K/M/G suffixes as src/dtw_main.c:46-58
@@ -93,6 +105,9 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   --invert                   reverse the reference events instead of query\n");
     fprintf(fp, "   --full-ref                 map to the full reference\n");
     fprintf(fp, "   --from-end                 map the end portion of the query instead of the beginning\n");
+    fprintf(fp, "   --sam                      output in SAM format\n");
+    fprintf(fp, "   --profile-cpu=yes|no       run the stages one after the other and report Parse/Events/Normalise/DTW time [no]\n");
+    fprintf(fp, "   --accel=yes|no             run the alignment on the accelerator [yes]; 'no' is an error: this build has no CPU path\n");
 }
 
 struct Read {
@@ -101,6 +116,7 @@ struct Read {
     size_t view_size = 0;
     sfa::Blow5Record rec;
     std::vector<sfa_event_t> ev;
+    std::vector<float> pa;             // --profile-cpu=yes: picoamps kept between the events and the normalise stage
     int64_t qstart = 0, qend = 0;
     bool keep = false;
     int status = 0;
@@ -182,7 +198,19 @@ class WorkerPool {
 
 }  // namespace
 
+static int dtw_run(int argc, char **argv);
+
 int dtw_main(int argc, char **argv) {
+    try {
+        return dtw_run(argc, argv);
+    } catch (const Fatal &e) {  // every helper thread has been joined by the unwinding (see Fatal)
+        fflush(stdout);
+        fprintf(stderr, "[sigfish-amd] ERROR: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+}
+
+static int dtw_run(int argc, char **argv) {
     const double t0 = realtime();
     static option lo[] = {{"threads", required_argument, 0, 't'},   {"batchsize", required_argument, 0, 'K'},
                           {"max-bytes", required_argument, 0, 'B'}, {"verbose", required_argument, 0, 'v'},
@@ -209,7 +237,7 @@ int dtw_main(int argc, char **argv) {
             case 'V': fprintf(stdout, "sigfish-amd %s\n", sfa_version()); exit(EXIT_SUCCESS);
             case 'h': fp_help = stdout; break;
             case 'p': o.prefix = atoi(optarg); break;
-            case 'q': o.query = atoi(optarg); if (o.query < 0) die("Query size should larger than 0."); break;
+            case 'q': o.query = atoi(optarg); if (o.query < 1) die("Query size should larger than 0."); break;
             case 'o': if (strcmp(optarg, "-") != 0 && !freopen(optarg, "wb", stdout)) die(std::string("failed to write the output to file ") + optarg); break;
             case 'a': o.flag |= F_SAM; break;
             case 'w': break;  // parsed and unused by the reference as well
@@ -220,7 +248,13 @@ int dtw_main(int argc, char **argv) {
             case 5: o.flag |= F_INV; break;
             case 6: o.flag |= F_REF; break;
             case 7: o.flag |= F_END; break;
-            case 8: case 9: case 12: case 13: break;  // CPU profiling / accel toggles / dead options: accepted, no effect
+            case 8: if (yes_or_no(optarg, "profile-cpu")) o.flag |= F_PRF; else o.flag &= ~F_PRF; break;  // src/dtw_main.c:213-214
+            case 9:  // src/dtw_main.c:215-220: the reference falls back to work_db(dtw_single) on its CPU; there is none here
+                if (!yes_or_no(optarg, "accel"))
+                    die("--accel=no: this build has no CPU alignment path (the stage only exists as gfx950 kernels); "
+                        "run the reference binary for a CPU run, or drop the option");
+                break;
+            case 12: case 13: break;  // dead options of the reference (--secondary, --meth-model): parsed, no effect
             case 10:
                 o.pore = optarg;
                 if (strcmp(optarg, "r9") && strcmp(optarg, "r10") && strcmp(optarg, "rna004")) die("Pore model should be r9, r10 or rna004");
@@ -312,7 +346,12 @@ int dtw_main(int argc, char **argv) {
     // Several devices (--device 0,1,...): reads shard by batch, every device holds its own copy of the reference
     // arrays (uploaded by sfa_init: a single process needs no collective), rows come back in batch order.
     const int n_ctx = (o.streams > 0 ? o.streams : 2) * static_cast<int>(o.devices.size());
-    std::vector<sfa_ctx_t *> ctxs(n_ctx, nullptr);
+    struct Contexts : std::vector<sfa_ctx_t *> {  // destroyed on every way out, after the helper threads that use them
+        using std::vector<sfa_ctx_t *>::vector;
+        ~Contexts() {
+            for (sfa_ctx_t *c : *this) sfa_destroy(c);
+        }
+    } ctxs(n_ctx, nullptr);
     for (int j = 0; j < n_ctx; ++j)
     {
         if (sfa_init(&ctxs[j], &sref, o.flag, o.devices[j % o.devices.size()]) != SFA_OK)
@@ -332,6 +371,11 @@ int dtw_main(int argc, char **argv) {
     // (one per context) and the output of batch i-2 run on helper threads, the main thread loads and pre-processes
     // batch i+1.  Batches are printed strictly in order, so the output is the same as the serial loop's. ----
     double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
+    // --profile-cpu=yes (src/dtw_main.c:213-214, src/sigfish.c:1021-1040): the stages of a batch run one after the other,
+    // each under its own timer, and the batches are not overlapped.  Host stages are wall time of their fan-out over -t
+    // threads, as in the reference; stages that run on the device are the device's own time (HIP events, sfa_get_profile).
+    const bool prf = (o.flag & F_PRF) != 0;
+    double t_parse = 0, t_events = 0, t_norm = 0, t_dtw_stage = 0;
     WorkerPool pool(o.threads);  // -t host threads, alive for the whole run
     int64_t total = 0, prefix_fail = 0, ignored = 0, too_short = 0, sum_bytes = 0;
     struct Slot {
@@ -377,8 +421,19 @@ int dtw_main(int argc, char **argv) {
         } else if (n > 0 && sfa_align_events(ctx, sl.evp.data(), sl.nev.data(), sl.qs.data(), sl.qe.data(), n, rows.data()) != SFA_OK) {
             die(std::string("alignment failed: ") + sfa_last_error());
         }
+        sfa_profile_t pr{};
+        if (prf && n > 0 && sfa_get_profile(ctx, &pr) != SFA_OK) die(std::string("sfa_get_profile failed: ") + sfa_last_error());
         std::lock_guard<std::mutex> lock(stat_mu);
         t_dtw += realtime() - a;
+        if (prf) {
+            if (gpu_events) {  // events and normalisation ran on the device, inside the same call
+                t_events += pr.events_ms * 1e-3;
+                t_norm += pr.normalise_ms * 1e-3;
+                t_dtw_stage += pr.total_ms * 1e-3;
+            } else {
+                t_dtw_stage += realtime() - a;  // the reference's timer around align_db (src/sigfish.c:1037-1040)
+            }
+        }
         if (gpu_events)
             for (int32_t i = 0; i < n; ++i) {
                 ignored += (sl.info[i].status & 2) != 0;
@@ -474,26 +529,53 @@ int dtw_main(int argc, char **argv) {
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
         a = realtime();
         std::atomic<int> bad(0);
-        pool.run(n, [&](int64_t i) {
+        auto parse_one = [&](int64_t i) {  // parse_single, src/sigfish.c:317-328
             Read &r = batch[i];
             std::string perr;
-            if (!(r.view ? reader.parse(r.view, r.view_size, &r.rec, &perr) : reader.parse(r.mem, &r.rec, &perr))) {
-                bad = 1;
-                return;
-            }
+            if (!(r.view ? reader.parse(r.view, r.view_size, &r.rec, &perr) : reader.parse(r.mem, &r.rec, &perr))) bad = 1;
             r.keep = false;
             r.ev.clear();
             r.status = 0;
+        };
+        auto events_one = [&](int64_t i, std::vector<float> &pa) {  // event_single, src/sigfish.c:330-378
+            Read &r = batch[i];
             const int64_t ns = static_cast<int64_t>(r.rec.raw.size());
-            if (ns > 0 && !gpu_events) {  // event_single + normalise_single
-                std::vector<float> pa(ns);
-                sfa::raw_to_picoamps(r.rec.raw.data(), ns, r.rec.digitisation, r.rec.offset, r.rec.range, pa.data());
-                r.ev = sfa::detect_events(pa.data(), ns, rna);
-                if (!r.ev.empty())
-                    r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), ns, pa.data(), o.prefix, o.query, o.flag, o.pore_flag,
-                                                       &r.qstart, &r.qend, &r.status);
+            pa.resize(ns);
+            sfa::raw_to_picoamps(r.rec.raw.data(), ns, r.rec.digitisation, r.rec.offset, r.rec.range, pa.data());
+            r.ev = sfa::detect_events(pa.data(), ns, rna);
+        };
+        auto normalise_one = [&](int64_t i, const std::vector<float> &pa) {  // normalise_single, src/sigfish.c:424-505
+            Read &r = batch[i];
+            if (!r.ev.empty())
+                r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), static_cast<int64_t>(r.rec.raw.size()), pa.data(), o.prefix, o.query,
+                                                   o.flag, o.pore_flag, &r.qstart, &r.qend, &r.status);
+        };
+        if (!prf) {  // one fan-out per batch, every read through all its host stages (work_per_single_read, src/sigfish.c:995-1001)
+            pool.run(n, [&](int64_t i) {
+                parse_one(i);
+                if (bad || gpu_events || batch[i].rec.raw.empty()) return;
+                std::vector<float> pa;
+                events_one(i, pa);
+                normalise_one(i, pa);
+            });
+        } else {  // stage by stage, each under its timer
+            double b = realtime();
+            pool.run(n, parse_one);
+            t_parse += realtime() - b;
+            if (!gpu_events && !bad) {
+                b = realtime();
+                pool.run(n, [&](int64_t i) {
+                    if (!batch[i].rec.raw.empty()) events_one(i, batch[i].pa);
+                });
+                t_events += realtime() - b;
+                b = realtime();
+                pool.run(n, [&](int64_t i) {
+                    if (!batch[i].rec.raw.empty()) normalise_one(i, batch[i].pa);
+                    std::vector<float>().swap(batch[i].pa);
+                });
+                t_norm += realtime() - b;
             }
-        });
+        }
         if (bad) die("error parsing a BLOW5 record");
         if (gpu_events) {  // pack the samples of the batch for one upload
             sl.raw_off.resize(n + 1);
@@ -537,6 +619,7 @@ int dtw_main(int argc, char **argv) {
             Slot *mine = &sl;
             sfa_ctx_t *c = ctxs[bi % n_ctx];
             gpu_pending[bi % n_ctx] = std::async(std::launch::async, [&align, mine, c] { align(*mine, c); });
+            if (prf) gpu_pending[bi % n_ctx].get();  // sectional mode: nothing of the next batch starts before this one is through
         }
         ++bi;
         total += n;
@@ -550,8 +633,17 @@ int dtw_main(int argc, char **argv) {
         output(slots[b % n_slots]);
     }
     for (Slot &sl : slots) sfa_pinned_free(sl.raw);
-    for (sfa_ctx_t *c : ctxs) sfa_destroy(c);
-    if (o.verbosity >= 3) {
+    if (o.verbosity >= 3 && prf) {  // the reference's lines, src/dtw_main.c:331-343
+        fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);
+        fprintf(stderr, "\n[dtw_main] total bytes: %.1f M", sum_bytes / 1e6);
+        fprintf(stderr, "\n[dtw_main] Data loading time: %.3f sec", t_load);
+        fprintf(stderr, "\n[dtw_main] Data processing time: %.3f sec", t_proc + t_dtw);
+        fprintf(stderr, "\n[dtw_main]     - Parse time: %.3f sec", t_parse);
+        fprintf(stderr, "\n[dtw_main]     - Events time: %.3f sec", t_events);
+        fprintf(stderr, "\n[dtw_main]     - Normalise time: %.3f sec", t_norm);
+        fprintf(stderr, "\n[dtw_main]     - DTW time: %.3f sec", t_dtw_stage);
+        fprintf(stderr, "\n[dtw_main] Data output time: %.3f sec\n", t_out);
+    } else if (o.verbosity >= 3) {
         fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld\n", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);
         fprintf(stderr, "[dtw_main] total bytes: %.1f M\n[dtw_main] Data loading time: %.3f sec\n", sum_bytes / 1e6, t_load);
         fprintf(stderr, "[dtw_main] Data processing time: %.3f sec (host stages) + %.3f sec (DTW stage, overlapped with the next batch)\n",

@@ -68,24 +68,32 @@ WarpPath band_traceback(const float *x, int32_t n, const float *y, int32_t rlen,
     return p;
 }
 
+std::vector<int32_t> path_to_pairs(const WarpPath &path) {
+    // path_to_map(), src/sigfish.c:530-571: per reference column the first/last query row; a column entered
+    // without advancing in the query (horizontal move) is blanked
+    const int32_t ref_st = path.py.front();
+    const int32_t len = path.py.back() - ref_st + 1;
+    std::vector<int32_t> pairs(2 * static_cast<size_t>(len), -1);
+    int32_t prev_q = -1;
+    for (size_t k = 0; k < path.px.size(); ++k) {
+        const int32_t ri = path.py[k] - ref_st, qi = path.px[k];
+        if (pairs[2 * ri] == -1) pairs[2 * ri] = qi;
+        pairs[2 * ri + 1] = qi;
+        if (prev_q == qi) pairs[2 * ri] = pairs[2 * ri + 1] = -1;
+        prev_q = qi;
+    }
+    return pairs;
+}
+
 std::string sam_record(const sfa_result_t &row, const WarpPath &path, const char *read_id, const char *rname, const sfa_event_t *ev,
                        int64_t qstart, int64_t qend, bool rna) {
     struct Pair {
         int32_t start, stop;
     };
-    // path_to_map(), src/sigfish.c:530-571: per reference column the first/last query row; a column entered
-    // without advancing in the query (horizontal move) is blanked
-    const int32_t ref_st = path.py.front();
-    const int32_t len = path.py.back() - ref_st + 1;
-    std::vector<Pair> map(len, Pair{-1, -1});
-    int32_t prev_q = -1;
-    for (size_t k = 0; k < path.px.size(); ++k) {
-        const int32_t ri = path.py[k] - ref_st, qi = path.px[k];
-        if (map[ri].start == -1) map[ri].start = qi;
-        map[ri].stop = qi;
-        if (prev_q == qi) map[ri].start = map[ri].stop = -1;
-        prev_q = qi;
-    }
+    const std::vector<int32_t> pairs = path_to_pairs(path);
+    const int32_t len = static_cast<int32_t>(pairs.size() / 2);
+    std::vector<Pair> map(len);
+    for (int32_t i = 0; i < len; ++i) map[i] = Pair{pairs[2 * i], pairs[2 * i + 1]};
     // r2qevent_map_to_ss(), src/sigfish.c:663-768
     if (rna) {
         const int32_t end = map[len - 1].stop;

@@ -23,6 +23,11 @@ struct WarpPath {
 // [col_st, col_end]: alignment columns in that array.  std_dtw: --dtw-std recurrence (row 0 cumulative from column 0).
 WarpPath band_traceback(const float *query, int32_t qlen, const float *y, int32_t rlen, int32_t col_st, int32_t col_end, bool std_dtw);
 
+// path_to_map(), src/sigfish.c:530-571: per reference column of the alignment the first / last query row mapped to it
+// (-1 / -1: a column the path crosses without advancing in the query); pairs[2*i], pairs[2*i+1] = start, stop of column
+// pos_st + i (layout of index_pair_t, src/sigfish.h:141-144).  Length = last column - first column + 1.
+std::vector<int32_t> path_to_pairs(const WarpPath &path);
+
 // path_to_map + r2qevent_map_to_ss + sam_str (src/sigfish.c:530-571, 663-794) for one read
 std::string sam_record(const sfa_result_t &row, const WarpPath &path, const char *read_id, const char *rname, const sfa_event_t *events,
                        int64_t qstart, int64_t qend, bool rna);

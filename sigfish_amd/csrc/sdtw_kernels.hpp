@@ -112,7 +112,22 @@ struct DpArgs {
     int32_t verify_planes; // floats per lane in a hand-over snapshot (max R + 1)
     float *verify;         // [quad][job][segment][in,out][verify_planes][64]
     int32_t *seg_fail;     // [quad] set when a hand-over does not match
+    // longest-remaining-first issue priority in the tail of the launch (see IssuePriority): columns per priority step,
+    // 0 = off; `started` counts the tasks that have begun (zeroed before the launch)
+    int32_t prio_unit;
+    unsigned *started;
+    unsigned long long *task_times;  // -DSFA_TASK_TIMES builds only (tools/task_times.py): [task][3] start, end (100 MHz ticks), SIMD position
 };
+
+// physical position of the executing wave: (xcc, se, sh, cu, simd) from HW_REG_XCC_ID / HW_REG_HW_ID, 14 bits.  Measured
+// on MI355X (tools/hwid_probe.hip): a grid of 1536 four-wave blocks covers 1024 distinct positions with 6 waves each.
+constexpr int kSimdSlots = 16384;
+__device__ __forceinline__ unsigned simd_position() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
+    const unsigned simd = (hw >> 4) & 3, cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+    return ((((xcc & 15) * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd;
+}
 
 // Neighbour exchange.  Lane g needs the bottom cost lane g-1 produced in the previous step.  On gfx950 a
 // `v_mov_b32_dpp row_shr:1` in this dependent position costs the SIMD ~40 issue cycles per step (measured,
@@ -201,6 +216,65 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
     return x * q + (x < rem ? x : rem) + i;
 }
 
+// Issue priority by remaining work, in the tail of a launch.  The SIMD's arbiter serves the OLDEST ready wave first, so
+// six waves that start together do not advance together: measured (tools/task_times.py, 6 equal tasks per SIMD) they end
+// at 4.5, 4.8, 6.7, 8.3, 9.9 and 11.2 ms -- the last ones run alone, at the 40 % of the SIMD's rate that one wave's
+// dependent chain can use, and the batch takes 11.2 ms where its share of a large one is 9.3.  s_setprio outranks age: a
+// wave lowers its own priority as its remaining columns fall below 4U, 2U, U, so whoever has the most left on a SIMD goes
+// first and the waves of a SIMD converge on a common finish (same test: 9.2 ... 9.7 ms).  While tasks are still waiting
+// for a slot that is the wrong policy -- everything on a SIMD would finish at once and its successors start late (measured:
+// +3 % on 100 000 reads) -- so it only applies once the LAST task of the launch has started: every wave counts itself in
+// `started` when it begins and looks at the counter every few windows until it reads n_tasks.
+__device__ __forceinline__ void set_issue_priority(int level) {
+    switch (level) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+struct IssuePriority {
+    int unit;       // U; 0 = off
+    int remaining;  // columns of the task still ahead when the current job starts (this job included)
+    int next_drop;  // `remaining - col` value at which the level falls next
+    int countdown;  // windows until the next look at the counter; < 0: the tail has begun
+    const unsigned *started;
+    unsigned n_tasks;
+    __device__ __forceinline__ void start(int u, int rem, unsigned *started_ctr, unsigned total) {
+        unit = u;
+        remaining = rem;
+        next_drop = 0x7fffffff;
+        countdown = 1;
+        started = started_ctr;
+        n_tasks = total;
+        if (unit > 0) {
+            // top level until the tail is seen: a wave left at the default (lowest) level next to waves that already lowered
+            // theirs step by step from 3 would starve, never reach its next look at the counter, and finish alone
+            set_issue_priority(3);
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(started_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __device__ __forceinline__ void update(int col) {  // at a window boundary, col columns into the current job
+        const int left = remaining - col;
+        const int level = left > 4 * unit ? 3 : (left > 2 * unit ? 2 : (left > unit ? 1 : 0));
+        set_issue_priority(level);
+        next_drop = level == 3 ? 4 * unit : (level == 2 ? 2 * unit : (level == 1 ? unit : -1));
+    }
+    __device__ __forceinline__ void at_window(int col) {
+        if (unit <= 0) return;
+        if (countdown >= 0) {
+            if (--countdown > 0) return;
+            countdown = 4;
+            const unsigned s = __builtin_amdgcn_readfirstlane(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (s < n_tasks) return;
+            countdown = -1;
+            update(col);
+        } else if (remaining - col <= next_drop) {
+            update(col);
+        }
+    }
+};
+
 // One anti-diagonal step for the R rows of this lane at reference level yv.
 //   c[r]   cost of row r at this lane's previous column ("left"); updated in place
 //   s[r]   start column carried with it (TRACK only)
@@ -283,7 +357,7 @@ __device__ __forceinline__ constexpr int ck_planes() { return R + 2; }
 template <int R, bool TRACK, bool STD, int RQ>
 __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
                                           const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<TRACK> &top,
-                                          const int job, float *ckp, const int T) {
+                                          const int job, float *ckp, const int T, IssuePriority &pr) {
     typename Vec<float, R>::type cv;
     typename Vec<int, R>::type sv;
 #pragma unroll
@@ -327,6 +401,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     // steady-state block carries no window-end test at all. ----
     int jqv = 0;  // last-row column of the next step
     for (int col = 0; col < rlen;) {
+        if (!TRACK) pr.at_window(col);
         const int wl = STD ? rlen : min(qlen, rlen - col);  // std_dtw has a single candidate: one "window"
         const int nb = wl >> 2, rm = wl & 3;
         float wmin = INFINITY;
@@ -391,20 +466,22 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         }
         col += wl;
     }
+    pr.remaining -= rlen;
 }
 
 // Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill (worth
 // 5-20 % on the small-batch shapes, whose steps are short).
 template <int R, bool TRACK, bool STD, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
-                                               const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T) {
+                                               const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T,
+                                               IssuePriority &pr) {
     if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
-        sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+        sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
     } else {
         if (rq == I) {
-            sweep_job<R, TRACK, STD, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+            sweep_job<R, TRACK, STD, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+            sweep_dispatch<R, TRACK, STD, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
         }
     }
 }
@@ -424,6 +501,10 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     const int lq = (qlen - 1) / R;  // lane / register holding the last query row (wave-uniform)
     const int rq = (qlen - 1) - lq * R;
     const int t_begin = sweep_begin(lq);
+#ifdef SFA_TASK_TIMES
+    const int dbg_task = cd.task_base + task_local;
+    if (a.task_times && lane == 0) a.task_times[3 * static_cast<int64_t>(dbg_task)] = wall_clock64();
+#endif
 
     float x[R];
     load_query_rows<R>(x, a, read, qlen, g);
@@ -437,12 +518,20 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     const int64_t ck_total = T ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
 
     const int jb = a.chunk_begin[chunk], je = a.chunk_begin[chunk + 1];
+    IssuePriority pr;
+    {
+        int cols = 0;
+        const bool on = !TRACK && a.prio_unit > 0;
+        if (on)
+            for (int job = jb; job < je; ++job) cols += a.job_len[job];
+        pr.start(on ? a.prio_unit : 0, cols, a.started, static_cast<unsigned>(a.n_tasks));
+    }
     for (int job = jb; job < je; ++job) {
         const int rlen = a.job_len[job];
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T);
+        sweep_dispatch<R, TRACK, STD>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
     }
 
     if (g == lq && read >= 0) {
@@ -453,6 +542,12 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         a.p_job[o] = top.job;
         if (TRACK) a.p_st[o] = top.st;
     }
+#ifdef SFA_TASK_TIMES
+    if (a.task_times && lane == 0) {
+        a.task_times[3 * static_cast<int64_t>(dbg_task) + 1] = wall_clock64();
+        a.task_times[3 * static_cast<int64_t>(dbg_task) + 2] = simd_position();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -842,6 +937,7 @@ struct FinalizeArgs {
     float *w_score;
     const int32_t *t_st;  // two-pass, second finalize: start columns [n_reads] then end columns [n_reads] from the trace kernel
     ResultRow *out;       // [n_reads]
+    const uint8_t *bad;   // [n_reads] 1: a query value is NaN or +-inf (sdtw_screen_kernel) -> the read is skipped
     int32_t n_reads, n_chunks;
     int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions
 };
@@ -906,6 +1002,30 @@ __global__ void __launch_bounds__(256) sdtw_verify_kernel(const DpArgs a, const 
     if (!__all(same) && lane == 0) a.seg_fail[quad] = 1;
 }
 
+// Non-finite query values.  The reference ABORTS on such a read -- a NaN or inf event makes the last row of the cost matrix
+// NaN, the window scan (src/sigfish.c:892-899) then returns min_pos = -1, update_aln() traces back from a column far outside
+// the matrix and dies in `assert(len >= 0)` (src/sigfish.c:611); observed with the compiled reference for one NaN event, an
+// all-NaN query (what z-normalising a zero-variance window gives) and one +inf event: tests/golden/degenerate/.  A batch
+// call cannot abort, so these reads are screened out up front: their rows come back valid = 0 (as for a read without
+// events: nothing is printed) and sfa_profile_t.non_finite_reads counts them.  One wave per read, coalesced.
+__global__ void __launch_bounds__(256) sdtw_screen_kernel(const float *queries, const int64_t *q_off, const int n, uint8_t *bad,
+                                                          unsigned *count) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = q_off[i], e = q_off[i + 1];
+    bool nf = false;
+    for (int64_t j = b + lane; j < e; j += 64) {
+        const unsigned u = __float_as_uint(queries[j]);
+        nf = nf || ((u & 0x7f800000u) == 0x7f800000u);  // exponent all ones: inf or NaN
+    }
+    const bool any = __any(nf);
+    if (lane == 0) {
+        bad[i] = any ? 1 : 0;
+        if (any) atomicAdd(count, 1u);
+    }
+}
+
 __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_reads) return;
@@ -934,7 +1054,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     r.valid = 0;
     r.pad = 0;
     int wjob = -1, wend = -1;
-    if (sl >= 0) {
+    if (sl >= 0 && !a.bad[i]) {
         const int64_t quad = sl >> 2, slot = sl & 3;
         float best = INFINITY, second = INFINITY;
         int end = -1, st = -1, job = -1;

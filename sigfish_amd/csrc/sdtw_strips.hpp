@@ -179,6 +179,11 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
         float4a bcn{};
         int4a bsn{};
         if (!FIRST) {
+            // Past column ncols - 1 (up to kBndPad words) this reads words nobody wrote for this read and job: left-overs
+            // of an earlier sweep, or the fill pattern of the allocation.  They only ever reach cells of columns >= ncols,
+            // and every cell depends on cells of its own or a LOWER column alone (up, diagonal, left) -- nothing of a
+            // column < ncols, the only ones that are read out, can see them.  (align_long() fills fresh allocations with
+            // a large finite pattern so that tools inspecting the buffers see no NaNs; correctness does not rest on it.)
             bcn = *reinterpret_cast<const float4a *>(bin_c + t0 + 4);
             if (TRACK) bsn = *reinterpret_cast<const int4a *>(bin_s + t0 + 4);
         }
@@ -344,6 +349,7 @@ struct StripFinalizeArgs {
     float *w_score;
     const int32_t *t_st, *t_end;  // mode 2 in
     ResultRow *out;  // rows of the whole batch
+    const uint8_t *bad;  // [reads of the batch] non-finite query (sdtw_screen_kernel): the read is skipped
     int32_t n_long, n_jobs;
     int32_t mode;  // 1: after pass 1 -> scores, contig, strand, mapq + winners; 2: after pass 2 -> positions
 };
@@ -389,6 +395,11 @@ __global__ void __launch_bounds__(64) sdtw_strip_finalize_kernel(const StripFina
     r.mapq = 0;
     r.valid = 1;
     r.pad = 0;
+    if (a.bad[a.reads[li]]) {  // the reference aborts on such a read (see sdtw_screen_kernel): skipped, like a read without events
+        r.valid = 0;
+        r.score = r.score2 = INFINITY;
+        job = -1;
+    }
     if (job >= 0 && ws >= 0) {
         r.rid = a.job_contig[job];
         r.strand = a.job_strand[job];

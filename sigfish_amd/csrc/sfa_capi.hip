@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -112,10 +113,17 @@ struct PinBuf {
 }  // namespace
 
 struct sfa_ctx {
+    // A GROUP context (sfa_init_devices) owns one ordinary context per listed device and nothing else: every batch is cut
+    // into contiguous read ranges, one per shard, which run concurrently; rows land in the caller's array in input order.
+    std::vector<sfa_ctx *> shards;
+    std::vector<int32_t> shard_lo;  // [shards+1] read ranges of the batch submitted with sfa_submit_batch
+
     int device = 0;
     uint32_t flag = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end, row strips start
+    hipEvent_t eev[4] = {nullptr, nullptr, nullptr, nullptr};  // sfa_align_raw: event detection start/end, normalisation start/end
+    bool eev_pending = false;
     int cu_count = 256;
 
     // tunables (sfa_set_option)
@@ -131,6 +139,7 @@ struct sfa_ctx {
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
+    int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
 
     // reference model (immutable after init)
     int32_t num_ref = 0, n_jobs = 0;
@@ -151,6 +160,11 @@ struct sfa_ctx {
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
         e_qoff, e_b0, e_b1, e_b2, e_flag, e_qev, e_pflag;
 
+    DevBuf d_bad, d_badcount;  // sdtw_screen_kernel: per-read flag, number of flagged reads
+    PinBuf h_badcount;
+    DevBuf d_started;     // counter of the fill's tasks that have begun (IssuePriority)
+    DevBuf d_times;       // -DSFA_TASK_TIMES builds: start / end / SIMD position of every wave-task of the last fill
+    int64_t n_times = 0;
     sfa::BatchPlan plan;  // plan of the batch being submitted (scratch included)
     sfa_profile_t prof{};
     bool prof_pending = false;
@@ -266,12 +280,14 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
     const int64_t bytes_per_read = (per + row_max) * 2 * 4 + ck_floats_per_read * 4;
     const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(n_long, c->opt_ckpt_budget / std::max<int64_t>(bytes_per_read, 1))));
     const size_t n_part = static_cast<size_t>(n_long) * n_jobs;
+    const size_t bndc_cap = c->d_bndc.cap;
     if ((rc = c->d_bndc.reserve(sizeof(float) * 2 * per * group)) || (rc = c->d_bnds.reserve(sizeof(int32_t) * 2 * row_max * group)) ||
         (rc = c->d_lbest.reserve(4 * n_part)) || (rc = c->d_lsecond.reserve(4 * n_part)) || (rc = c->d_lend.reserve(4 * n_part)) ||
         (rc = c->d_lwin.reserve(4 * 5 * static_cast<size_t>(n_long))) ||
         (rc = c->d_lck.reserve(sizeof(float) * std::max<int64_t>(ck_floats_per_read, 1) * group)))
         return rc;
     hipStream_t st = c->stream;
+    if (c->d_bndc.cap != bndc_cap) HIP_TRY(hipMemsetAsync(c->d_bndc.p, 0x7f, c->d_bndc.cap, st));  // fresh allocation: 3.4e38 everywhere (see the pad note in sdtw_strips.hpp)
     HIP_TRY(hipMemcpyAsync(c->d_long.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
     const char *ds = c->d_long.as<char>();
     const bool std_dtw = (c->flag & SFA_DTW) != 0;
@@ -320,6 +336,7 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         fa.t_st = sa.t_st;
         fa.t_end = sa.t_end;
         fa.out = d_out;
+        fa.bad = c->d_bad.as<uint8_t>();
         fa.n_long = gn;
         fa.n_jobs = n_jobs;
         const dim3 block(256), fgrid((gn + 63) / 64), fblock(64);
@@ -369,6 +386,7 @@ int align_sliced(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         sum.ckpt_bytes = std::max(sum.ckpt_bytes, c->prof.ckpt_bytes);
         sum.n_tasks += c->prof.n_tasks;
         sum.n_chunks = std::max(sum.n_chunks, c->prof.n_chunks);
+        sum.non_finite_reads += c->prof.non_finite_reads;
     }
     c->prof = sum;
     return SFA_OK;
@@ -433,6 +451,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         (rc = c->d_psecond.reserve(4 * n_part)) || (rc = c->d_wjob.reserve(4 * (size_t)n)) || (rc = c->d_wend.reserve(4 * (size_t)n)) ||
         (rc = c->d_tst.reserve(8 * (size_t)n)) || (rc = c->d_wscore.reserve(4 * (size_t)n)))
         return rc;
+    if ((rc = c->d_bad.reserve(static_cast<size_t>(n))) || (rc = c->d_badcount.reserve(64)) || (rc = c->h_badcount.reserve(64))) return rc;
     if (plan.single_pass && (rc = c->d_pst.reserve(4 * n_part))) return rc;
     if (!plan.single_pass && plan.ck_floats > 0 && (rc = c->d_ck.reserve(sizeof(float) * plan.ck_floats))) return rc;
     const int32_t verify_planes = plan.max_R + 1;
@@ -488,6 +507,14 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.verify_planes = verify_planes;
     da.verify = c->d_verify.as<float>();
     da.seg_fail = c->d_segfail.as<int32_t>();
+    da.prio_unit = static_cast<int32_t>(c->opt_prio_unit);
+    if ((rc = c->d_started.reserve(64))) return rc;
+    da.started = c->d_started.as<unsigned>();
+#ifdef SFA_TASK_TIMES
+    if ((rc = c->d_times.reserve(24 * static_cast<size_t>(std::max(da.n_tasks, 1))))) return rc;
+    da.task_times = c->d_times.as<unsigned long long>();
+    c->n_times = da.n_tasks;
+#endif
 
     FinalizeArgs fz{};
     fz.slot_of_read = reinterpret_cast<const int32_t *>(ds + o_slot);
@@ -505,11 +532,18 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     fz.w_score = da.w_score;
     fz.t_st = c->d_tst.as<int32_t>();
     fz.out = d_out;
+    fz.bad = c->d_bad.as<uint8_t>();
     fz.n_reads = n;
     fz.n_chunks = n_chunks;
     const dim3 fgrid((n + 255) / 256), fblock(256);
 
+    if (da.prio_unit > 0) HIP_TRY(hipMemsetAsync(c->d_started.p, 0, 4, st));
     HIP_TRY(hipEventRecord(c->ev[0], st));
+    // reads with a NaN / inf query value are skipped (the reference aborts on them, see sdtw_screen_kernel)
+    HIP_TRY(hipMemsetAsync(c->d_badcount.p, 0, 4, st));
+    hipLaunchKernelGGL(sfa::sdtw_screen_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_queries, da.q_off, n, c->d_bad.as<uint8_t>(),
+                       c->d_badcount.as<unsigned>());
+    KERNEL_TRY();
     if (n_quads > 0) {
         if (plan.single_pass)
             launch_fill<true>(plan.max_R, std_dtw, da, st);
@@ -547,6 +581,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         HIP_TRY(hipEventRecord(c->ev[5], st));
         if ((rc = align_long(c, d_queries, da.q_off, long_reads, long_max, d_out))) return rc;
     }
+    HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[4], st));
 
     c->prof.cells = (plan.query_events + long_events) * c->total_cols;
@@ -591,6 +626,16 @@ int resolve_profile(sfa_ctx *c) {
         a += l;
         c->long_pending = false;
     }
+    c->prof.events_ms = c->prof.normalise_ms = 0;
+    if (c->eev_pending) {
+        float e1 = 0, e2 = 0;
+        HIP_TRY(hipEventElapsedTime(&e1, c->eev[0], c->eev[1]));
+        HIP_TRY(hipEventElapsedTime(&e2, c->eev[2], c->eev[3]));
+        c->prof.events_ms = e1;
+        c->prof.normalise_ms = e2;
+        c->eev_pending = false;
+    }
+    c->prof.non_finite_reads = c->h_badcount.p ? *c->h_badcount.as<unsigned>() : 0;  // (copied before ev[4], which has been waited for)
     c->prof.fill_ms = a;
     c->prof.trace_ms = d;
     c->prof.finalize_ms = t - a - d;
@@ -607,12 +652,62 @@ const char *sfa_last_error(void) { return g_err.c_str(); }
 void sfa_set_error_(const char *msg) { g_err = msg ? msg : ""; }  // for the host-side units of this library
 const char *sfa_version(void) { return SFA_VERSION; }
 
-int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {
-    if (!out || !ref || ref->num_ref <= 0 || !ref->ref_lengths || !ref->forward)
-        return fail(SFA_EINVAL, "sfa_init: null or empty reference");
+}  // extern "C"
+
+// The reference event model as the kernels want it, built once on the host: every (contig,strand) array in the
+// reference's processing order (contig ascending, '+' before '-', src/sigfish.c:870-960) inside one buffer, +inf around
+// each (cells of columns < 0 and past the end evaluate to +inf, see sweep_begin() in the kernels).
+struct HostRef {
+    int32_t num_ref = 0, n_jobs = 0;
+    int64_t total_cols = 0;
+    std::vector<float> packed;
+    std::vector<int64_t> job_off;
+    std::vector<int32_t> job_len, job_contig, ref_off, ref_len;
+    std::vector<int8_t> job_strand;
+};
+
+static int pack_reference(const sfa_ref_t *ref, uint32_t flag, HostRef *h) {
+    if (!ref || ref->num_ref <= 0 || !ref->ref_lengths || !ref->forward) return fail(SFA_EINVAL, "sfa_init: null or empty reference");
     const bool rna = (flag & SFA_RNA) != 0;
     if (!rna && !ref->reverse) return fail(SFA_EINVAL, "sfa_init: DNA needs reverse arrays");
     if ((flag & SFA_DTW) && !rna) return fail(SFA_EINVAL, "sfa_init: --dtw-std is RNA only (src/dtw_main.c:249-252)");
+    const int strands = rna ? 1 : 2;
+    h->num_ref = ref->num_ref;
+    h->n_jobs = ref->num_ref * strands;
+    h->job_off.resize(h->n_jobs);
+    h->job_len.resize(h->n_jobs);
+    h->job_contig.resize(h->n_jobs);
+    h->job_strand.resize(h->n_jobs);
+    h->ref_off.resize(ref->num_ref);
+    h->ref_len.assign(ref->ref_lengths, ref->ref_lengths + ref->num_ref);
+    int64_t total = sfa::kRefPad;
+    for (int32_t r = 0; r < ref->num_ref; ++r) {
+        const int32_t rl = ref->ref_lengths[r];
+        if (rl <= 0) return fail(SFA_EINVAL, "contig %d has non-positive length %d", r, rl);
+        h->ref_off[r] = ref->ref_st_offset ? ref->ref_st_offset[r] : 0;
+        for (int s = 0; s < strands; ++s) {
+            const int32_t j = r * strands + s;
+            h->job_off[j] = total;
+            h->job_len[j] = rl;
+            h->job_contig[j] = r;
+            h->job_strand[j] = s == 0 ? '+' : '-';
+            total += rl + sfa::kRefPad;
+            h->total_cols += rl;
+        }
+    }
+    h->packed.assign(total, INFINITY);
+    for (int32_t j = 0; j < h->n_jobs; ++j) {
+        const float *src = (h->job_strand[j] == '+') ? ref->forward[h->job_contig[j]] : ref->reverse[h->job_contig[j]];
+        if (!src) return fail(SFA_EINVAL, "missing reference array for contig %d", h->job_contig[j]);
+        memcpy(&h->packed[h->job_off[j]], src, sizeof(float) * h->job_len[j]);
+    }
+    return SFA_OK;
+}
+
+// One context on one device.  `peer`: a context that already holds the packed arrays -- they then travel device to
+// device (hipMemcpyPeer: xGMI between the GPUs of a node) instead of crossing PCIe once more (one broadcast
+// of the reference event model, root = the first device).
+static int create_context(sfa_ctx **out, const HostRef &h, uint32_t flag, int device, const sfa_ctx *peer) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(SFA_ENODEV, "no HIP device available (this library has no CPU fallback)");
@@ -627,7 +722,10 @@ int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {
     c->device = device;
     c->flag = flag;
     c->cu_count = prop.multiProcessorCount;
-    c->num_ref = ref->num_ref;
+    c->num_ref = h.num_ref;
+    c->n_jobs = h.n_jobs;
+    c->total_cols = h.total_cols;
+    c->h_job_len = h.job_len;
     auto bail = [&](int rc) {
         sfa_destroy(c);
         return rc;
@@ -635,72 +733,118 @@ int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
-
-    // job list in the reference's processing order: contig ascending, '+' before '-' (src/sigfish.c:870-960)
-    const int strands = rna ? 1 : 2;
-    c->n_jobs = ref->num_ref * strands;
-    std::vector<int64_t> job_off(c->n_jobs);
-    std::vector<int32_t> job_contig(c->n_jobs), ref_off(ref->num_ref);
-    std::vector<int8_t> job_strand(c->n_jobs);
-    c->h_job_len.resize(c->n_jobs);
-    int64_t total = sfa::kRefPad;
-    for (int32_t r = 0; r < ref->num_ref; ++r) {
-        const int32_t rl = ref->ref_lengths[r];
-        if (rl <= 0) return bail(fail(SFA_EINVAL, "contig %d has non-positive length %d", r, rl));
-        ref_off[r] = ref->ref_st_offset ? ref->ref_st_offset[r] : 0;
-        for (int s = 0; s < strands; ++s) {
-            const int32_t j = r * strands + s;
-            job_off[j] = total;
-            c->h_job_len[j] = rl;
-            job_contig[j] = r;
-            job_strand[j] = s == 0 ? '+' : '-';
-            total += rl + sfa::kRefPad;
-            c->total_cols += rl;
-        }
-    }
-    // +inf padding: cells of columns < 0 (and past the end) evaluate to +inf, see sweep_begin() in the kernels
-    std::vector<float> packed(total, INFINITY);
-    for (int32_t j = 0; j < c->n_jobs; ++j) {
-        const float *src = (job_strand[j] == '+') ? ref->forward[job_contig[j]] : ref->reverse[job_contig[j]];
-        if (!src) return bail(fail(SFA_EINVAL, "missing reference array for contig %d", job_contig[j]));
-        memcpy(&packed[job_off[j]], src, sizeof(float) * c->h_job_len[j]);
-    }
+    for (auto &e : c->eev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     int rc;
-    if ((rc = c->d_ref.reserve(sizeof(float) * total)) || (rc = c->d_job_off.reserve(sizeof(int64_t) * c->n_jobs)) ||
+    const size_t ref_bytes = sizeof(float) * h.packed.size();
+    if ((rc = c->d_ref.reserve(ref_bytes)) || (rc = c->d_job_off.reserve(sizeof(int64_t) * c->n_jobs)) ||
         (rc = c->d_job_len.reserve(sizeof(int32_t) * c->n_jobs)) || (rc = c->d_job_contig.reserve(sizeof(int32_t) * c->n_jobs)) ||
-        (rc = c->d_job_strand.reserve(c->n_jobs)) || (rc = c->d_ref_len.reserve(sizeof(int32_t) * ref->num_ref)) ||
-        (rc = c->d_ref_off.reserve(sizeof(int32_t) * ref->num_ref)))
+        (rc = c->d_job_strand.reserve(c->n_jobs)) || (rc = c->d_ref_len.reserve(sizeof(int32_t) * h.num_ref)) ||
+        (rc = c->d_ref_off.reserve(sizeof(int32_t) * h.num_ref)))
         return bail(rc);
 #define UP(dst, src, bytes) \
     if (hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(SFA_ENODEV, "upload of reference model failed"))
-    UP(c->d_ref.p, packed.data(), sizeof(float) * total);
-    UP(c->d_job_off.p, job_off.data(), sizeof(int64_t) * c->n_jobs);
-    UP(c->d_job_len.p, c->h_job_len.data(), sizeof(int32_t) * c->n_jobs);
-    UP(c->d_job_contig.p, job_contig.data(), sizeof(int32_t) * c->n_jobs);
-    UP(c->d_job_strand.p, job_strand.data(), c->n_jobs);
-    UP(c->d_ref_len.p, ref->ref_lengths, sizeof(int32_t) * ref->num_ref);
-    UP(c->d_ref_off.p, ref_off.data(), sizeof(int32_t) * ref->num_ref);
+    if (peer) {
+        if (hipMemcpyPeer(c->d_ref.p, device, peer->d_ref.p, peer->device, ref_bytes) != hipSuccess)
+            return bail(fail(SFA_ENODEV, "device-to-device copy of the reference model (%d -> %d) failed", peer->device, device));
+    } else {
+        UP(c->d_ref.p, h.packed.data(), ref_bytes);
+    }
+    UP(c->d_job_off.p, h.job_off.data(), sizeof(int64_t) * c->n_jobs);
+    UP(c->d_job_len.p, h.job_len.data(), sizeof(int32_t) * c->n_jobs);
+    UP(c->d_job_contig.p, h.job_contig.data(), sizeof(int32_t) * c->n_jobs);
+    UP(c->d_job_strand.p, h.job_strand.data(), c->n_jobs);
+    UP(c->d_ref_len.p, h.ref_len.data(), sizeof(int32_t) * h.num_ref);
+    UP(c->d_ref_off.p, h.ref_off.data(), sizeof(int32_t) * h.num_ref);
 #undef UP
     *out = c;
     return SFA_OK;
 }
 
+// ---- group contexts: the same entry points over several devices ---------------------------------------------------
+// contiguous read range of shard r: [r*n/G, (r+1)*n/G)
+static void shard_ranges(int32_t n, size_t g, std::vector<int32_t> *lo) {
+    lo->resize(g + 1);
+    for (size_t r = 0; r <= g; ++r) (*lo)[r] = static_cast<int32_t>(static_cast<int64_t>(n) * static_cast<int64_t>(r) / static_cast<int64_t>(g));
+}
+
+// run fn(shard index) for every shard, one host thread each (HIP's current device and sfa_last_error are per thread);
+// the first failure's code and message become the caller's
+template <typename F>
+static int for_each_shard(sfa_ctx *g, F fn) {
+    const size_t G = g->shards.size();
+    std::vector<std::future<std::pair<int, std::string>>> jobs;
+    for (size_t r = 1; r < G; ++r)
+        jobs.push_back(std::async(std::launch::async, [&fn, r] {
+            const int rc = fn(r);
+            return std::make_pair(rc, rc ? g_err : std::string());
+        }));
+    int rc = fn(0);
+    std::string msg = rc ? g_err : std::string();
+    for (auto &j : jobs) {
+        const auto res = j.get();
+        if (res.first && !rc) {
+            rc = res.first;
+            msg = res.second;
+        }
+    }
+    if (rc) g_err = msg;
+    return rc;
+}
+
+extern "C" {
+
+int sfa_init(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, int device) {
+    if (!out) return fail(SFA_EINVAL, "sfa_init: null context pointer");
+    HostRef h;
+    if (int rc = pack_reference(ref, flag, &h)) return rc;
+    return create_context(out, h, flag, device, nullptr);
+}
+
+int sfa_init_devices(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, const int *devices, int n_devices) {
+    if (!out || !devices || n_devices <= 0) return fail(SFA_EINVAL, "sfa_init_devices: null or empty device list");
+    HostRef h;
+    if (int rc = pack_reference(ref, flag, &h)) return rc;
+    sfa_ctx *g = new sfa_ctx();
+    g->flag = flag;
+    g->device = devices[0];
+    for (int i = 0; i < n_devices; ++i) {
+        sfa_ctx *c = nullptr;
+        // one upload from the host, then device to device from the first shard
+        if (int rc = create_context(&c, h, flag, devices[i], g->shards.empty() ? nullptr : g->shards[0])) {
+            sfa_destroy(g);
+            return rc;
+        }
+        g->shards.push_back(c);
+    }
+    *out = g;
+    return SFA_OK;
+}
+
 void sfa_destroy(sfa_ctx_t *c) {
     if (!c) return;
+    if (!c->shards.empty()) {
+        for (sfa_ctx *sh : c->shards) sfa_destroy(sh);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_ref, &c->d_job_off, &c->d_job_len, &c->d_job_contig, &c->d_job_strand, &c->d_ref_len, &c->d_ref_off,
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount})
         b->release();
     c->h_stage.release();
     c->h_out.release();
     c->h_small.release();
     c->h_flags.release();
     c->h_long.release();
+    c->h_badcount.release();
     for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->eev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -708,6 +852,11 @@ void sfa_destroy(sfa_ctx_t *c) {
 
 int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SFA_EINVAL, "sfa_set_option: null argument");
+    if (!c->shards.empty()) {
+        for (sfa_ctx *sh : c->shards)
+            if (int rc = sfa_set_option(sh, key, value)) return rc;
+        return SFA_OK;
+    }
     const std::string k(key);
     if (k == "single_pass") {
         c->opt_single_pass = value != 0;
@@ -738,6 +887,9 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
         c->opt_widen_below = value;
+    } else if (k == "prio_unit") {
+        if (value < 0 || value > (1 << 28)) return fail(SFA_EINVAL, "prio_unit must be 0 (off) .. 2^28");
+        c->opt_prio_unit = value;
     } else if (k == "waves_per_simd") {
         if (value < 1 || value > 8) return fail(SFA_EINVAL, "waves_per_simd must be 1..8");
         c->opt_waves_per_simd = value;
@@ -749,6 +901,9 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
 
 int sfa_align_batch_device(sfa_ctx_t *c, const float *d_queries, const int64_t *q_off, int32_t n, sfa_result_t *d_out, int sync) {
     if (!c || !q_off || n < 0 || (n > 0 && (!d_queries || !d_out))) return fail(SFA_EINVAL, "sfa_align_batch_device: bad argument");
+    if (!c->shards.empty())
+        return fail(SFA_EINVAL, "sfa_align_batch_device: device-resident buffers belong to one device; use a single-device context "
+                                "(sfa_init) per GPU, or the host-buffer entry points on a group context");
     HIP_TRY(hipSetDevice(c->device));
     // the pinned staging area is reused by every call: the previous batch must have left it
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -763,6 +918,16 @@ int sfa_align_batch_device(sfa_ctx_t *c, const float *d_queries, const int64_t *
 
 int sfa_submit_batch(sfa_ctx_t *c, const float *queries, const int64_t *q_off, int32_t n) {
     if (!c || !q_off || n < 0 || (n > 0 && !queries)) return fail(SFA_EINVAL, "sfa_submit_batch: bad argument");
+    if (!c->shards.empty()) {  // every shard queues its contiguous range of reads on its own device
+        shard_ranges(n, c->shards.size(), &c->shard_lo);
+        c->pending_n = -1;
+        const int rc = for_each_shard(c, [&](size_t r) {
+            const int32_t lo = c->shard_lo[r], hi = c->shard_lo[r + 1];
+            return sfa_submit_batch(c->shards[r], queries, q_off + lo, hi - lo);  // (q_off holds absolute offsets into queries)
+        });
+        if (!rc) c->pending_n = n;
+        return rc;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));  // one batch in flight per context
     c->pending_n = -1;
@@ -796,6 +961,11 @@ int sfa_wait_batch(sfa_ctx_t *c, sfa_result_t *out, int32_t n) {
     if (c->pending_n < 0) return fail(SFA_EINVAL, "sfa_wait_batch: no batch was submitted");
     if (c->pending_n != n) return fail(SFA_EINVAL, "sfa_wait_batch: %d reads were submitted, %d asked for", c->pending_n, n);
     c->pending_n = -1;
+    if (!c->shards.empty())  // rows of shard r go to out[lo_r, hi_r): input order, no gather step in a single process
+        return for_each_shard(c, [&](size_t r) {
+            const int32_t lo = c->shard_lo[r], hi = c->shard_lo[r + 1];
+            return sfa_wait_batch(c->shards[r], out ? out + lo : nullptr, hi - lo);
+        });
     if (n == 0) return SFA_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -844,6 +1014,19 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
     if (prefix_size < 0) return fail(SFA_EINVAL, "sfa_align_raw: automatic query start (-p -1) needs the host stages");
     if (query_size <= 0) return fail(SFA_EINVAL, "sfa_align_raw: query_size must be positive");
     if (n == 0) return SFA_OK;
+    if (!c->shards.empty()) {
+        std::vector<int32_t> lo;
+        shard_ranges(n, c->shards.size(), &lo);
+        return for_each_shard(c, [&](size_t r) {
+            const int32_t a = lo[r], b = lo[r + 1];
+            if (a == b) return static_cast<int>(SFA_OK);
+            std::vector<int64_t> off(b - a + 1);  // the shard's sample offsets start at 0
+            for (int32_t i = a; i <= b; ++i) off[i - a] = raw_off[i] - raw_off[a];
+            return sfa_align_raw_ex(c->shards[r], raw + raw_off[a], off.data(), scaling + 3 * static_cast<size_t>(a), b - a, prefix_size,
+                                    query_size, rows + a, info + a,
+                                    query_events ? query_events + static_cast<size_t>(a) * static_cast<size_t>(query_size) : nullptr);
+        });
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int64_t total = raw_off[n] - raw_off[0];
@@ -907,6 +1090,7 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
     // measured: 76 us against 1.5 ms for a 512-read batch, 2.1 ms against 1.3 ms for 16 Ki reads (it does ~1.3x the work of
     // the sequential walk, in 64x more waves): used while the batch cannot fill the chip with one read per lane pair
     ea.use_peak_flags = (c->opt_ev_parallel_peaks && n <= 8192) ? 1 : 0;
+    HIP_TRY(hipEventRecord(c->eev[0], st));
     if (ea.use_flags) hipLaunchKernelGGL(sfa::ev_prefix_par_kernel, dim3(n), dim3(64), 0, st, ea);  // flags what it cannot do exactly
     hipLaunchKernelGGL(sfa::ev_prefix_kernel, lane_grid, lane_block, 0, st, ea);
     hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, st, ea);
@@ -914,6 +1098,7 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
     hipLaunchKernelGGL(sfa::ev_peaks_kernel, dim3((n + 31) / 32), dim3(64), 0, st, ea);  // two lanes per read (all reads, or the flagged ones)
     hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, st, ea);
     KERNEL_TRY();
+    HIP_TRY(hipEventRecord(c->eev[1], st));
     if ((rc = c->h_small.reserve(16 * (size_t)n))) return rc;  // page-locked: event counts, then the three raw-coordinate columns
     int32_t *nev = c->h_small.as<int32_t>();
     HIP_TRY(hipMemcpyAsync(nev, c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -968,6 +1153,7 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
         return rc;
     HIP_TRY(hipMemcpyAsync(c->e_qstart.p, qstart.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->e_qoff.p, q_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(c->eev[2], st));
     sfa::QueryArgs qa{c->e_evmean.as<float>(), c->e_evoff.as<int64_t>(), c->e_qstart.as<int64_t>(), c->e_qoff.as<int64_t>(),
                       c->d_queries.as<float>(), n};
     hipLaunchKernelGGL(sfa::ev_query_kernel, dim3(n), dim3(64), 0, st, qa);  // one wave per read
@@ -984,6 +1170,8 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
         HIP_TRY(hipMemcpyAsync(query_events, c->e_qev.p, qe_bytes, hipMemcpyDeviceToHost, st));
     }
     KERNEL_TRY();
+    HIP_TRY(hipEventRecord(c->eev[3], st));
+    c->eev_pending = true;
     // the queries must be complete before align_device's uploads reuse the pinned staging area; same stream, in order
     if ((rc = align_device(c, c->d_queries.as<float>(), q_off.data(), n, c->d_out.as<ResultRow>()))) return rc;
     int32_t *b0 = c->h_small.as<int32_t>(), *b1 = b0 + n;
@@ -1026,6 +1214,11 @@ void sfa_pinned_free(void *p) {
 
 int sfa_sync(sfa_ctx_t *c) {
     if (!c) return fail(SFA_EINVAL, "null context");
+    if (!c->shards.empty()) {
+        for (sfa_ctx *sh : c->shards)
+            if (int rc = sfa_sync(sh)) return rc;
+        return SFA_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return resolve_profile(c);
@@ -1033,11 +1226,48 @@ int sfa_sync(sfa_ctx_t *c) {
 
 int sfa_get_profile(sfa_ctx_t *c, sfa_profile_t *p) {
     if (!c || !p) return fail(SFA_EINVAL, "null argument");
+    if (!c->shards.empty()) {  // the shards run side by side: times are the slowest shard's, counts add up
+        sfa_profile_t sum{};
+        for (sfa_ctx *sh : c->shards) {
+            sfa_profile_t q;
+            if (int rc = sfa_get_profile(sh, &q)) return rc;
+            sum.fill_ms = std::max(sum.fill_ms, q.fill_ms);
+            sum.trace_ms = std::max(sum.trace_ms, q.trace_ms);
+            sum.finalize_ms = std::max(sum.finalize_ms, q.finalize_ms);
+            sum.total_ms = std::max(sum.total_ms, q.total_ms);
+            sum.events_ms = std::max(sum.events_ms, q.events_ms);
+            sum.normalise_ms = std::max(sum.normalise_ms, q.normalise_ms);
+            sum.cells += q.cells;
+            sum.fill_launches += q.fill_launches;
+            sum.n_tasks += q.n_tasks;
+            sum.ckpt_bytes += q.ckpt_bytes;
+            sum.segment_reruns += q.segment_reruns;
+            sum.non_finite_reads += q.non_finite_reads;
+            sum.ckpt_interval = std::max(sum.ckpt_interval, q.ckpt_interval);
+            sum.n_chunks = std::max(sum.n_chunks, q.n_chunks);
+            sum.n_segments = std::max(sum.n_segments, q.n_segments);
+        }
+        *p = sum;
+        return SFA_OK;
+    }
     if (int rc = resolve_profile(c)) return rc;
     *p = c->prof;
     return SFA_OK;
 }
 
-void *sfa_stream(sfa_ctx_t *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+void *sfa_stream(sfa_ctx_t *c) { return (c && c->shards.empty()) ? static_cast<void *>(c->stream) : nullptr; }
+
+int sfa_n_devices(sfa_ctx_t *c) { return !c ? 0 : (c->shards.empty() ? 1 : static_cast<int>(c->shards.size())); }
+
+#ifdef SFA_TASK_TIMES
+// measurement builds only (tools/task_times.py): [task][3] = start tick, end tick (100 MHz), SIMD position of the last fill
+int64_t sfa_debug_task_times(sfa_ctx_t *c, unsigned long long *out, int64_t cap_tasks) {
+    if (!c || !out) return -1;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    const int64_t n = std::min<int64_t>(cap_tasks, c->n_times);
+    if (n > 0 && hipMemcpy(out, c->d_times.p, 24 * static_cast<size_t>(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif
 
 }  // extern "C"

@@ -181,9 +181,11 @@ int sfa_select_query(sfa_event_t *events, int64_t n_events, const int16_t *raw, 
     return keep ? 1 : 0;
 }
 
-int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname, const sfa_event_t *events,
-                int64_t qstart, int64_t qend, const float *ref_array, int32_t ref_len, int32_t ref_st_offset, uint32_t flag) {
-    if (!buf || !r || !read_id || !rname || !events || !ref_array || qend <= qstart || !r->valid || r->rid < 0) return SFA_EINVAL;
+}  // extern "C"
+namespace {
+// the winner's warp path from its result row: query in DP order, columns of the strand's own array
+sfa::WarpPath path_of_row(const sfa_result_t *r, const sfa_event_t *events, int64_t qstart, int64_t qend, const float *ref_array,
+                          int32_t ref_len, int32_t ref_st_offset, uint32_t flag) {
     const bool rna = (flag & SFA_RNA) != 0;
     const int32_t qlen = static_cast<int32_t>(qend - qstart);
     std::vector<float> q(static_cast<size_t>(qlen));
@@ -193,7 +195,30 @@ int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_i
     const bool plus = r->strand == '+';
     const int32_t st = plus ? r->pos_st - ref_st_offset : ref_len - (r->pos_end - ref_st_offset);
     const int32_t en = plus ? r->pos_end - ref_st_offset : ref_len - (r->pos_st - ref_st_offset);
-    const sfa::WarpPath path = sfa::band_traceback(q.data(), qlen, ref_array, ref_len, st, en, (flag & SFA_DTW) != 0);
+    return sfa::band_traceback(q.data(), qlen, ref_array, ref_len, st, en, (flag & SFA_DTW) != 0);
+}
+}  // namespace
+extern "C" {
+
+int32_t sfa_r2qevent_map(const sfa_result_t *r, const sfa_event_t *events, int64_t qstart, int64_t qend, const float *ref_array,
+                         int32_t ref_len, int32_t ref_st_offset, uint32_t flag, int32_t *pairs, int32_t cap_pairs) {
+    if (!r || !events || !ref_array || qend <= qstart || !r->valid || r->rid < 0) return SFA_EINVAL;
+    const int32_t need = r->pos_end - r->pos_st + 1;  // r2qevent_size, src/sigfish.c:610-612
+    if (need <= 0) return SFA_EINVAL;
+    if (!pairs || cap_pairs < need) return pairs ? SFA_ERANGE : need;
+    const sfa::WarpPath path = path_of_row(r, events, qstart, qend, ref_array, ref_len, ref_st_offset, flag);
+    if (path.px.empty()) return SFA_EINVAL;
+    const std::vector<int32_t> p = sfa::path_to_pairs(path);
+    if (static_cast<int32_t>(p.size() / 2) != need) return SFA_EINVAL;
+    memcpy(pairs, p.data(), sizeof(int32_t) * p.size());
+    return need;
+}
+
+int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_id, const char *rname, const sfa_event_t *events,
+                int64_t qstart, int64_t qend, const float *ref_array, int32_t ref_len, int32_t ref_st_offset, uint32_t flag) {
+    if (!buf || !r || !read_id || !rname || !events || !ref_array || qend <= qstart || !r->valid || r->rid < 0) return SFA_EINVAL;
+    const bool rna = (flag & SFA_RNA) != 0;
+    const sfa::WarpPath path = path_of_row(r, events, qstart, qend, ref_array, ref_len, ref_st_offset, flag);
     if (path.px.empty()) return SFA_EINVAL;
     const std::string line = sfa::sam_record(*r, path, read_id, rname, events, qstart, qend, rna);
     if (line.size() + 1 > cap) return SFA_ERANGE;

@@ -114,3 +114,26 @@ def test_cli_errors_like_reference(models):
         assert r.returncode != 0 and msg in r.stderr.decode()
     r = subprocess.run([BIN, "dtw", c["fasta"], c["blow5"]], capture_output=True)
     assert r.returncode != 0 and "--kmer-model" in r.stderr.decode()
+
+
+@pytest.mark.parametrize("extra", [[], ["--host-events"]])
+def test_cli_profile_cpu_prints_the_reference_stage_timers(models, extra):
+    """--profile-cpu=yes (src/dtw_main.c:213-214): stage by stage, with the reference's Parse / Events / Normalise / DTW
+    lines on stderr (src/dtw_main.c:336-341); the output itself does not change."""
+    import re
+    c = load_case("dna_default")
+    cmd = [BIN, "dtw", "--kmer-model", models[6], "--profile-cpu=yes", *extra, c["fasta"], c["blow5"]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+    err = r.stderr.decode()
+    t = {}
+    for key in ("Parse", "Events", "Normalise", "DTW"):
+        m = re.search(r"\[dtw_main\]     - %s time: ([0-9.]+) sec" % key, err)
+        assert m, (key, err)
+        t[key] = float(m.group(1))
+    assert re.search(r"\[dtw_main\] Data processing time: [0-9.]+ sec\n", err)
+    assert t["DTW"] > 0 and t["Events"] >= 0  # (five reads: the host stages round to 0.000)
+    # without the switch the four lines are not printed
+    r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], *extra, c["fasta"], c["blow5"]], capture_output=True, timeout=300)
+    assert r.returncode == 0 and "- Parse time" not in r.stderr.decode() and r.stdout.decode() == c["out_text"]

@@ -462,19 +462,40 @@ def test_column_segments_on_tie_heavy_data(oracle, seed):
             assert_rows_equal(al.align_db(q, q_off), want)
 
 
-def test_non_finite_queries_do_not_hang():
-    """NaN / inf query values are outside the contract (the reference is undefined there); the call must still return."""
-    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=16, seed=2)
-    q = q.copy()
-    q[5] = np.nan
-    q[int(q_off[3]) + 7] = np.inf
-    q[int(q_off[6]):int(q_off[7])] = np.nan
-    q[int(q_off[9]):int(q_off[10])] = 0.0   # a constant query (what a zero-variance read would give before dividing)
+def test_degenerate_and_non_finite_queries_against_the_reference():
+    """tests/golden/degenerate (oracle/make_golden_degenerate.py, answered by the compiled reference's own align_db):
+    constant, quantised and two-level queries -- the reference prints rows (exact ties: score == score2, mapq 0), and so
+    must we, bit for bit; a read with a NaN or inf event -- the reference ABORTS (assert in update_aln, src/sigfish.c:611:
+    reference_on_non_finite.txt), a batch call cannot, so that read comes back valid = 0 and is counted, and the other
+    reads of the batch are unaffected."""
+    import os
+    from tests.util import GOLD
+    z = np.load(os.path.join(GOLD, "degenerate", "degenerate.npz"))
+    ref, flag, _, _, _ = synth.workload("ncov_r9_dna_q250", n_reads=16, seed=2)
+    assert "Assertion `len >= 0' failed" in open(os.path.join(GOLD, "degenerate", "reference_on_non_finite.txt")).read()
     for mode in ("two_pass", "single_pass", "wide4_dense"):
         with _aligner(ref, flag, mode) as al:
-            rows = al.align_db(q, q_off)
-        clean = [i for i in range(16) if i not in (0, 3, 6)]
-        assert (rows["valid"] == 1).all() and (rows["rid"][clean] == 0).all()
+            assert_rows_equal(al.align_db(z["queries_finite"], z["q_off"]), z["rows_finite"].view(S.RESULT_DTYPE))
+            assert al.profile()["non_finite_reads"] == 0
+            got = al.align_db(z["queries"], z["q_off"])
+            assert al.profile()["non_finite_reads"] == len(z["non_finite"])
+        assert got.tobytes() == z["rows"].view(S.RESULT_DTYPE).tobytes()
+        assert list(np.flatnonzero(got["valid"] == 0)) == list(z["non_finite"])
+
+
+def test_non_finite_long_query_is_skipped_too():
+    """The same screen in front of the row-strip path (queries beyond 2048 events)."""
+    rng = np.random.default_rng(5)
+    ref = _small_ref(rng, [700, 400], False)
+    lens = [2500, 40, 2300]
+    q = rng.normal(size=sum(lens)).astype(np.float32)
+    q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    with S.Aligner(ref, 0, device=0) as al:
+        clean = al.align_db(q, q_off)
+        q[100] = np.nan
+        got = al.align_db(q, q_off)
+        assert al.profile()["non_finite_reads"] == 1
+    assert got["valid"].tolist() == [0, 1, 1] and got["rid"][0] == -1 and got[1:].tobytes() == clean[1:].tobytes()
 
 
 def test_options_are_validated():

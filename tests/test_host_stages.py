@@ -94,6 +94,55 @@ def test_sam_rows_from_reference_alignments(name):
     assert got == want
 
 
+@pytest.mark.parametrize("name", ["dna_sam", "rna_sam"])
+def test_r2qevent_map_equals_path_to_map_on_the_full_matrix(name, oracle):
+    """sfa_r2qevent_map (band re-fill between the winner's start and end columns) against path_to_map (src/sigfish.c:530-571)
+    applied to the traceback of the FULL cost matrix, as update_aln does (src/sigfish.c:599-613)."""
+    c = load_case(name)
+    ref = S.RefModel.from_fasta(c["fasta"], c["levels"], c["k"], c["flag"], c["query_size"])
+    rows = np.zeros(len(c["rid"]), S.RESULT_DTYPE)
+    for f in ("rid", "pos_st", "pos_end", "score", "score2", "strand", "mapq"):
+        rows[f] = c[f]
+    rows["valid"] = 1
+    vi = 0
+    rna = bool(c["flag"] & S.RNA)
+    for rid, nraw, ev, keep, qs, qe in _pipeline(c):
+        if not keep:
+            continue
+        r = rows[vi]
+        vi += 1
+        plus = r["strand"] == ord("+")
+        j = int(r["rid"])
+        arr = ref.forward[j] if plus else ref.reverse[j]
+        got = S.r2qevent_map(r, ev, qs, qe, arr, int(ref.st_offset[j]), c["flag"])
+        x = ev["mean"][qs:qe].astype(np.float32)
+        if rna:
+            x = x[::-1].copy()  # src/sigfish.c:860-866
+        off, rl = int(ref.st_offset[j]), len(arr)
+        end = int(r["pos_end"]) - off if plus else rl - (int(r["pos_st"]) - off)
+        cost = oracle.subsequence(x, arr)
+        px, py = oracle.subsequence_path(cost, end)
+        n = int(r["pos_end"]) - int(r["pos_st"]) + 1
+        assert py[-1] - py[0] + 1 == n and got.shape == (n, 2)
+        want = np.full((n, 2), -1, np.int32)
+        prev = -1
+        for qi, ri in zip(px, py - py[0]):
+            if want[ri, 0] == -1:
+                want[ri, 0] = qi
+            want[ri, 1] = qi
+            if prev == qi:
+                want[ri] = -1
+            prev = qi
+        assert np.array_equal(got, want)
+    assert vi == len(rows)
+    # size query, short buffer, unaligned row
+    L = __import__("sigfish_amd._lib", fromlist=["load"]).load()
+    bad = rows[0].copy()
+    bad["rid"] = -1
+    with pytest.raises(S.SfaError):
+        S.r2qevent_map(bad, ev, qs, qe, arr, 0, c["flag"])
+
+
 def test_blow5_reader_rejects_corrupt_files(tmp_path):
     """Flipped bytes, truncation, garbage size fields: an error (or, where the damage hits nothing that is checked, a
     normal read), never a crash or an exception across the C boundary."""

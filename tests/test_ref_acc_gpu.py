@@ -1,0 +1,46 @@
+"""The drop-in, built and run (VERDICT r1 "prove the drop-in by building it"): `make -C oracle ref-acc` compiles the
+reference with acc=1 (-DHAVE_ACC=1, its Makefile:34-36) and oracle/ref_acc.patch -- the binding INTEGRATION.md shows: the
+init / align_db / teardown slots of src/sigfish.c:200-204, 1003-1015, 221-225 calling sfa_init / sfa_align_events (+
+sfa_r2qevent_map for SAM) / sfa_destroy -- and links libsigfish_amd.so.  oracle/_ref/ref_driver_acc then runs THE
+REFERENCE'S OWN batch loop (load_db -> process_db -> output_db, src/dtw_main.c:299-326; its own parse, event detection,
+normalisation, paf_str and sam_str) with the alignment stage on the GPU.  Its stdout must be byte-identical to what the
+unpatched reference printed (tests/golden/cases/*.out, tests/golden/random/*.out)."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+from tests.util import GOLD, ROOT, case_names, load_case
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver_acc")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/ref_driver_acc not built (`make -C oracle ref-acc`)")]
+
+
+def _run(k, args, fasta, blow5):
+    cmd = [DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), *args, fasta, blow5]
+    r = subprocess.run(cmd, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout.decode()
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_reference_batch_loop_through_the_hook(name):
+    c = load_case(name)
+    assert _run(c["k"], [str(a) for a in c["args"]], c["fasta"], c["blow5"]) == c["out_text"]
+
+
+RANDOM_CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "random", "*.args")))
+
+
+@pytest.mark.parametrize("name", RANDOM_CASES)
+def test_reference_batch_loop_through_the_hook_random_signals(name):
+    k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
+    got = _run(int(k), args, os.path.join(GOLD, "data", fasta), os.path.join(GOLD, "random", blow5))
+    assert got == open(os.path.join(GOLD, "random", name + ".out")).read()
+
+
+def test_small_batches_through_the_hook():
+    """-K 3: several batches through align_db, context reused between them."""
+    c = load_case("rna_sam")
+    assert _run(c["k"], [str(a) for a in c["args"]] + ["-K", "3"], c["fasta"], c["blow5"]) == c["out_text"]
