@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="also time sfa_align_batch with HOST query/result buffers (PCIe-inclusive; never `value`)")
     ap.add_argument("--opt", action="append", default=[], help="sfa_set_option key=value (tuning experiments)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (raw BLOW5 -> PAF through the command line)")
+    ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads in the generated BLOW5 files of the end-to-end leg")
     args = ap.parse_args()
 
     # ---- ranks: the launcher's, or our own (never a re-exec of a process that has touched the GPU) ----------------
@@ -103,6 +105,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.zeros(1, device=dev)
+    # PyTorch's wheel bundles its own HIP runtime next to the system one the library links; they coexist in one process when
+    # torch's is initialised FIRST.  Do not rely on import order: check it.
+    assert torch.cuda.is_initialized(), "torch.cuda must be initialised before libsigfish_amd.so makes its first HIP call"
     force_dist = os.environ.get("SFA_DIST_FORCE") == "1"  # rehearse the RCCL path with one rank
     if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=dev)
@@ -180,19 +186,32 @@ def main():
     achieved = alg_bytes / kern_s / 1e9
     cells_per_s_kernel = cells / kern_s
     ops_per_cell = 49 / 16  # counted from the shipped R=16 fill ISA: 49 VALU per 16-cell step
-    # HBM bytes per fill launch from the committed PMC passes of this build (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-    # KB -> bytes; MI355X_MICROARCH.md section HBM).  Only quoted for the configuration that was profiled.
+    # HBM bytes per fill launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB -> bytes;
+    # MI355X_MICROARCH.md section HBM).  Counters cannot be collected inside this run, so the figure is only quoted when the
+    # newest profile under profiles/ was taken on THIS build of the library (profiles/<tag>_build_id.txt == sfa_build_id())
+    # on this workload; otherwise `traffic` is null and `traffic_source` says why.
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_v15_pmc_summary.csv")
-    if os.path.exists(pmc) and args.workload == "ncov_r9_dna_q250" and n == 100_000 and not args.opt:
-        vals = {}
-        for line in open(pmc).read().splitlines()[1:]:
-            kname, counter, _, mean, _ = line.rsplit(",", 4)
-            if "sdtw_fill_kernel" in kname:
-                vals[counter] = float(mean)
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-            traffic_src = "profiles/r01_v15_pmc_summary.csv (separate rocprofv3 --pmc passes of this build, same workload)"
+    import glob
+    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_build_id.txt")))
+    if not (args.workload == "ncov_r9_dna_q250" and n == 100_000 and not args.opt):
+        traffic_src = "not profiled: only the default workload and options have committed PMC passes"
+    elif not stamps:
+        traffic_src = "no profile under profiles/ carries a build id"
+    else:
+        tag = os.path.basename(stamps[-1])[:-len("_build_id.txt")]
+        prof_build = open(stamps[-1]).read().strip()
+        pmc = os.path.join(ROOT, "profiles", tag + "_pmc_summary.csv")
+        if prof_build != S.build_id():
+            traffic_src = f"stale: profiles/{tag} was taken on build {prof_build}, this library is build {S.build_id()}"
+        elif os.path.exists(pmc):
+            vals = {}
+            for line in open(pmc).read().splitlines()[1:]:
+                kname, counter, _, mean, _ = line.rsplit(",", 4)
+                if "sdtw_fill_kernel" in kname:
+                    vals[counter] = float(mean)
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+                traffic_src = f"profiles/{tag}_pmc_summary.csv (separate rocprofv3 --pmc passes of build {prof_build}, same workload)"
     out = {
         "metric": ("reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)" if args.workload == "ncov_r9_dna_q250"
                    else f"reads/s (sDTW alignment stage: {args.workload})"),
@@ -208,6 +227,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "library_build": S.build_id(),
         "config": {"workload": args.workload, "reads_per_gpu": n, "query_events": qlen, "ref_kmers": int(ref.ref_lengths.sum()),
                    "strands": strands, "sharding": f"reads x{world}", "cells_per_read_full": qlen * cols},
         "dp_cells_per_s": round(cells * world * args.steps / elapsed, 1),
@@ -259,6 +279,15 @@ def main():
                                "parity_on_sample": bool(got.tobytes() == want.tobytes())}
         out["speedup_vs_cpu_baseline"] = round(value / (sample / dt), 1)
     al.close()
+    # ---- end to end (SURVEY.md 8d "plus end-to-end wall"): raw BLOW5 -> PAF through `sigfish-amd dtw`, whole process, on files
+    # generated here; extra keys, never `value`.  After al.close(): the command line wants the GPU to itself.
+    if world == 1 and not args.no_e2e and args.workload == "ncov_r9_dna_q250":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import e2e_bench
+        try:
+            out["end_to_end"] = e2e_bench.measure(reads=args.e2e_reads, threads=min(host_cores(), 16))
+        except Exception as e:  # the headline line must not depend on scratch space for multi-GB files
+            out["end_to_end"] = {"error": str(e)[:300]}
     print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -100,6 +100,7 @@ typedef struct {
     /* reads of the batch whose query holds a NaN or +-inf event.  The reference aborts on such a read (assert in update_aln,
      * src/sigfish.c:611); here they are skipped: their rows come back with valid = 0. */
     int64_t non_finite_reads;
+    int64_t lds_ckpt;      /* 1: the fill kept its rolling checkpoints in LDS (ckpt_interval is then the sparse HBM store's) */
 } sfa_profile_t;
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */
@@ -162,6 +163,10 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
 
 /* Tuning knobs (all optional): "single_pass" (0/1: track start columns in one pass instead of fill + trace),
  * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = qlen+16),
+ * "lds_ckpt" (1 = default: where every shape of the batch has <= 16 rows per lane and the DTW is the subsequence one, the
+ * fill keeps its last two snapshots in LDS and writes one to HBM only when a window becomes a read's best so far, plus a
+ * sparse store every 32768 steps for pass 2 to back off to; 0 = every snapshot to HBM), "prio_unit" (columns per step of
+ * the fill's longest-remaining-first issue priority in the tail of a launch; 0 = off),
  * "waves_per_simd" (1..8, occupancy target used when splitting the contig list), "lane_widening" (0 = auto by batch
  * size, 1/2/4 = fixed: rows per lane / w and lanes per read * w, the small-batch latency shapes), "widen_below"
  * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 5), "min_slice_reads" (a batch whose
@@ -194,6 +199,9 @@ void sfa_destroy(sfa_ctx_t *ctx);
 
 const char *sfa_last_error(void);
 const char *sfa_version(void);
+/* Identity of the device code this library was built from (hash of the kernel and launch sources): profiles/ files are
+ * stamped with it, so that numbers measured on one build are never quoted for another. */
+const char *sfa_build_id(void);
 
 /* ---- host-side helpers on the same path (no GPU needed) ------------------------------------------------ */
 

@@ -26,7 +26,7 @@ class SfaProfile(C.Structure):
                 ("total_ms", C.c_double), ("cells", C.c_int64), ("fill_launches", C.c_int64),
                 ("ckpt_interval", C.c_int64), ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64),
                 ("n_chunks", C.c_int64), ("n_segments", C.c_int64), ("segment_reruns", C.c_int64),
-                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64)]
+                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64), ("lds_ckpt", C.c_int64)]
 
 
 class SfaPlanInfo(C.Structure):
@@ -47,7 +47,7 @@ class SfaEvent(C.Structure):
 
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_host.py::test_library_exports_every_declared_symbol)
 SYMBOLS = ["sfa_init", "sfa_init_devices", "sfa_n_devices", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
-           "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_gen_ref_record",
+           "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_build_id", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_r2qevent_map", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close", "sfa_inflate_zlib", "sfa_device_memory"]
 
@@ -88,6 +88,7 @@ def load():
     L.sfa_destroy.restype = None
     L.sfa_last_error.restype = C.c_char_p
     L.sfa_version.restype = C.c_char_p
+    L.sfa_build_id.restype = C.c_char_p
     L.sfa_gen_ref_record.argtypes = [C.c_char_p, C.c_int32, f32p, C.c_uint32, C.c_uint32, C.c_int32, f32p, f32p,
                                      i32p]
     L.sfa_gen_ref_record.restype = C.c_int32

@@ -37,6 +37,10 @@ def version():
     return _lib.load().sfa_version().decode()
 
 
+def build_id():
+    return _lib.load().sfa_build_id().decode()
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

@@ -52,6 +52,9 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #ifndef SFA_FILL32_WAVES
 #define SFA_FILL32_WAVES 4  // the R = 32 shapes: 128 VGPRs (a handful of spills outside the loop); 81.5 -> 79.6 ms at q = 500
 #endif
+#ifndef SFA_LCK_WAVES
+#define SFA_LCK_WAVES 4  // the fill with its checkpoints in LDS: 2 x 17 planes x 256 B per wave -> four blocks of four waves per CU
+#endif
 #ifndef SFA_TRACE_WAVES
 #define SFA_TRACE_WAVES 4  // waves per SIMD pass 2 (R <= 16) is register-budgeted for: 128 VGPRs; 3.49 -> 3.28 ms per 100 k reads against 144 VGPRs / 3 waves
 #endif
@@ -112,6 +115,15 @@ struct DpArgs {
     int32_t verify_planes; // floats per lane in a hand-over snapshot (max R + 1)
     float *verify;         // [quad][job][segment][in,out][verify_planes][64]
     int32_t *seg_fail;     // [quad] set when a hand-over does not match
+    // rolling checkpoints in LDS (LCK kernels, see LdsCkpt): the record of every (quad, chunk)'s current best window,
+    // [task][R_max + 1 planes][64 lanes]; the step index of that snapshot per (task, slot) (-1: none, start from scratch);
+    // the best score of every read so far over all its tasks (float bits, for the save filter); the winning chunk per read
+    float *best_rec;
+    int32_t *best_e;
+    unsigned *g_best;
+    int32_t *w_chunk;
+    int32_t best_planes;   // planes per record (R of the largest class + 1)
+    int32_t coarse_every;  // every coarse_every-th LDS snapshot also goes to the HBM checkpoint store (ck_shift = 9 + log2 of it)
     // longest-remaining-first issue priority in the tail of the launch (see IssuePriority): columns per priority step,
     // 0 = off; `started` counts the tasks that have begun (zeroed before the launch)
     int32_t prio_unit;
@@ -196,7 +208,7 @@ struct Top2 {
         st = -1;
         job = -1;
     }
-    __device__ __forceinline__ void offer(float sc, int32_t pos, int32_t start, int32_t j) {
+    __device__ __forceinline__ bool offer(float sc, int32_t pos, int32_t start, int32_t j) {
         const bool top = !(sc > best);
         const bool sec = !(sc > second);
         second = top ? best : (sec ? sc : second);
@@ -204,6 +216,7 @@ struct Top2 {
         end = top ? pos : end;
         if (TRACK) st = top ? start : st;
         job = top ? j : job;
+        return top;
     }
 };
 
@@ -352,12 +365,71 @@ __device__ __forceinline__ int sweep_begin(int lq) { return lq - ((lq + kStepsPe
 template <int R>
 __device__ __forceinline__ constexpr int ck_planes() { return R + 2; }
 
+// Rolling checkpoints in LDS (the LCK kernels).  Pass 2 only ever restores ONE snapshot per read -- the one in front of the
+// window that finally wins -- yet the plain scheme spills every snapshot of every quad to HBM (13 GB per 100 000-read
+// launch).  Here a wave keeps its last two snapshots (every 512 steps) in LDS and copies one to HBM only when a window has
+// just become a read's best so far (a handful of times per read): the snapshot pass 2 would pick for that window, i.e. the
+// last one taken at least trace_margin + 3 steps before the window's first cell.  The host caps the margin at
+// 512 - qlen - 3, so that snapshot is always one of the two on hand (see save()).  A save is skipped when another task of
+// the same read has already seen a strictly better score (g_best, atomic min over float bits): that window cannot win.
+// What the record of a (quad, chunk) holds at the end is the snapshot for the chunk's best window whenever that window can
+// be the read's winner.  If the path turns out to start before the snapshot, pass 2 backs off to the sparse HBM
+// checkpoints (every coarse_every-th snapshot is also stored there, as before) and finally to the start of the strand.
+constexpr int kLdsCkShift = 9;
+constexpr int kLdsCkPlanes = 17;  // R <= 16 costs + dprev
+struct LdsCkpt {
+    float *buf;        // this lane's column of the wave's two buffers: buf[(j & 1) * kLdsCkPlanes * 64 + plane * 64]
+    int count;         // snapshots taken in the current job (1-based index of the last one)
+    int e0, e1;        // step index of the snapshot held by buffer 0 / 1
+    float *rec;        // this lane's column of the task's HBM record
+    int32_t *rec_e;    // [4] per slot
+    unsigned *g_best;  // this lane's read (valid where owner)
+    __device__ __forceinline__ void begin_job() { count = 0; }
+    template <int R, typename CV>
+    __device__ __forceinline__ void snapshot(const CV &cv, float dprev, int e) {
+        count += 1;
+        float *b = buf + (count & 1) * (kLdsCkPlanes * 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) b[r * 64] = cv[r];
+        b[R * 64] = dprev;
+        if (count & 1)
+            e1 = e;
+        else
+            e0 = e;
+    }
+    // at the end of a window that began at step e_ws (steps since t_begin) and became the best of some read(s) of the quad:
+    // improved = ballot of the lanes owning the last query row of those reads.  All 64 lanes are active here.
+    template <int R, int L>
+    __device__ __forceinline__ void save(unsigned long long improved, float wmin, int e_ws, int margin, int lq, int job) {
+        const int lane = threadIdx.x & 63;
+        const int owner_lane = (lane & ~(L - 1)) + lq;
+        const bool mine = (improved >> owner_lane) & 1;
+        const unsigned wb = __float_as_uint(__shfl(wmin, owner_lane));  // costs are non-negative: bit order = value order
+        unsigned old = 0;
+        if (mine && lane == owner_lane) old = atomicMin(g_best, wb);
+        old = __shfl(old, owner_lane);
+        if (!(mine && wb <= old)) return;
+        // the snapshot pass 2 would choose: index kk = floor((e_ws - margin - 3) / 512), taken at the first block boundary
+        // at or after kk * 512.  margin <= 512 - wl - 3, hence kk >= count - 1: still in its buffer.
+        const int from = e_ws - margin - 3;
+        const int kk = from > 0 ? (from >> kLdsCkShift) : 0;
+        if (kk > 0) {
+            const float *b = buf + (kk & 1) * (kLdsCkPlanes * 64);
+#pragma unroll
+            for (int r = 0; r <= R; ++r) rec[r * 64] = b[r * 64];
+        }
+        if (lane == owner_lane) rec_e[lane / L] = kk > 0 ? ((kk & 1) ? e1 : e0) : -1;
+        (void)job;
+    }
+};
+
 // One (contig,strand) sweep of a quad.  RQ >= 0: the register holding the last query row is a compile-time
 // constant (hot specialisation); RQ < 0: it is the wave-uniform value rq (indexed v_mov).
-template <int R, bool TRACK, bool STD, int RQ>
+template <int R, bool TRACK, bool STD, int RQ, bool LCK = false, int L = 16>
 __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
                                           const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<TRACK> &top,
-                                          const int job, float *ckp, const int T, IssuePriority &pr) {
+                                          const int job, float *ckp, const int T, IssuePriority &pr, LdsCkpt *lck = nullptr,
+                                          const bool owner = false) {
     typename Vec<float, R>::type cv;
     typename Vec<int, R>::type sv;
 #pragma unroll
@@ -372,8 +444,25 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     int e = 0;               // steps executed so far; the next step is t = t_begin + e
     int ck_next = T ? T : 0x7fffffff;
     const int ck_last = T ? ((rlen > 4 ? rlen - 4 : 0) >> a.ck_shift) << a.ck_shift : 0;  // last k*T that is stored
+    if (LCK) {
+        lck->begin_job();
+        ck_next = 1 << kLdsCkShift;
+    }
     auto maybe_checkpoint = [&]() {  // at a block boundary: snapshot the state BEFORE step t_begin + e
-        if (!TRACK && T) {
+        if (LCK) {
+            if (e >= ck_next) {
+                lck->template snapshot<R>(cv, dprev, e);
+                ck_next += 1 << kLdsCkShift;
+                // every coarse_every-th one also goes to the sparse HBM store (what pass 2 backs off to), same format as below
+                if (T && (lck->count & (a.coarse_every - 1)) == 0 && (lck->count << kLdsCkShift) <= ck_last) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
+                    ckp[R * 64] = dprev;
+                    ckp[(R + 1) * 64] = __int_as_float(e);
+                    ckp += ck_planes<R>() * 64;
+                }
+            }
+        } else if (!TRACK && T) {
             if (e >= ck_next && ck_next <= ck_last) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
@@ -458,7 +547,11 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             ycur = ynext;
         }
         if (!STD) {
-            top.offer(wmin, TRACK ? wpos : col, wst, job);  // cost-only: the window is identified by its first column
+            const bool became_best = top.offer(wmin, TRACK ? wpos : col, wst, job);  // cost-only: the window is identified by its first column
+            if (LCK) {
+                const unsigned long long improved = __ballot(became_best && owner);
+                if (improved) lck->template save<R, L>(improved, wmin, col + e_main, a.trace_margin, lq, job);
+            }
         } else {  // std_dtw: the single candidate C[n-1][m-1]
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
             const int sl = TRACK ? ((RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq])) : 0;
@@ -471,23 +564,24 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
 
 // Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill (worth
 // 5-20 % on the small-batch shapes, whose steps are short).
-template <int R, bool TRACK, bool STD, int I = 0>
+template <int R, bool TRACK, bool STD, bool LCK = false, int L = 16, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
                                                const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T,
-                                               IssuePriority &pr) {
+                                               IssuePriority &pr, LdsCkpt *lck = nullptr, bool owner = false) {
     if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
-        sweep_job<R, TRACK, STD, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
+        sweep_job<R, TRACK, STD, -1, LCK, L>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
     } else {
         if (rq == I) {
-            sweep_job<R, TRACK, STD, I>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
+            sweep_job<R, TRACK, STD, I, LCK, L>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
+            sweep_dispatch<R, TRACK, STD, LCK, L, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
         }
     }
 }
 
-template <int R, int L, bool TRACK, bool STD>
-__device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i) {
+template <int R, int L, bool TRACK, bool STD, bool LCK = false>
+__device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i,
+                                          float *lds_ck = nullptr) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
     const int quad_local = task_local - chunk * cd.n_quads;
     const int quad = cd.quad_base + quad_local;
@@ -526,12 +620,22 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
             for (int job = jb; job < je; ++job) cols += a.job_len[job];
         pr.start(on ? a.prio_unit : 0, cols, a.started, static_cast<unsigned>(a.n_tasks));
     }
+    LdsCkpt lck;
+    if (LCK) {
+        const int64_t task = static_cast<int64_t>(quad) * a.n_chunks + chunk;
+        lck.buf = lds_ck + (threadIdx.x >> 6) * (2 * kLdsCkPlanes * 64) + lane;
+        lck.rec = a.best_rec + task * a.best_planes * 64 + lane;
+        lck.rec_e = a.best_e + task * 4;
+        lck.g_best = a.g_best + (read >= 0 ? read : 0);
+        lck.e0 = lck.e1 = 0;
+        if (g == lq && read >= 0) lck.rec_e[slot] = -1;  // nothing saved yet: pass 2 starts the strand from scratch
+    }
     for (int job = jb; job < je; ++job) {
         const int rlen = a.job_len[job];
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr);
+        sweep_dispatch<R, TRACK, STD, LCK, L>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, &lck, g == lq && read >= 0);
     }
 
     if (g == lq && read >= 0) {
@@ -736,9 +840,11 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 // compiled in, so a batch without long queries does not pay the long variant's register budget.
 // SEG: the column-segment variant (cost-only sDTW, small batches) is its own kernel, so that the throughput kernel's code
 // is not touched by it.
-template <int MAXR, bool TRACK, bool STD, bool SEG = false>
-__global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES))) sdtw_fill_kernel(const DpArgs a) {
+// LCK: rolling checkpoints in LDS (LdsCkpt) -- two snapshots of 17 planes per wave, 34 KB per block, four blocks per CU.
+template <int MAXR, bool TRACK, bool STD, bool SEG = false, bool LCK = false>
+__global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES)))) sdtw_fill_kernel(const DpArgs a) {
     static_assert(!SEG || (!TRACK && !STD), "segments: cost-only subsequence DTW");
+    static_assert(!LCK || (!TRACK && !STD && !SEG && MAXR <= 16), "LDS checkpoints: cost-only subsequence DTW, R <= 16");
     // blockIdx -> task.  Blocks are dealt to the 8 XCDs round-robin, so with the identity every XCD sees every class and
     // every chunk of the job list evenly -- what this kernel wants: the reference arrays (hundreds of KB to a few MB) stay
     // resident in every XCD's L2 anyway, whereas the classes differ in speed.  Measured (A/B builds, fill ms): identity
@@ -765,13 +871,14 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES 
     const int tl = task - cd.task_base;
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
+    __shared__ float lds_ck[LCK ? 4 * 2 * kLdsCkPlanes * 64 : 1];
 #define SFA_SHAPE(RR, LL)                                                                    \
     case (RR) * 256 + (LL):                                                                  \
         if constexpr (MAXR >= (RR)) {                                                        \
             if constexpr (SEG)                                                               \
                 fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */   \
             else                                                                             \
-                fill_body<RR, LL, TRACK, STD>(a, cd, tl, lds_f, lds_i);                      \
+                fill_body<RR, LL, TRACK, STD, LCK>(a, cd, tl, lds_f, lds_i, lds_ck);         \
         }                                                                                    \
         break;
     switch (cd.R * 256 + cd.lanes) {
@@ -792,7 +899,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (MAXR <= 16 ? SFA_FILL_WAVES 
 // ---------------------------------------------------------------------------------------------------------
 struct ResultRow;  // below
 
-template <int R, int L, bool STD>
+template <int R, int L, bool STD, bool LCK = false>
 __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st, float *lds_f,
                                            int *lds_i) {
     const int quad = cd.quad_base + quad_local;
@@ -836,14 +943,35 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     int back = 1;
     int res_st = -1, res_end = -1;
     const unsigned long long owner = __ballot(g == lq);  // the lanes that own a last query row
+    // LCK: the first attempt restores the snapshot the fill saved for the winning window (the record of the read's winning
+    // chunk); only if the path began before it do the sparse HBM checkpoints (k, as computed above with their interval) come in
+    bool use_rec = false;
+    const float *recp = nullptr;
+    int rec_e = -1;
+    if (LCK && !done) {
+        const int64_t task = static_cast<int64_t>(quad) * a.n_chunks + a.w_chunk[read];
+        rec_e = a.best_e[task * 4 + slot];
+        recp = a.best_rec + task * a.best_planes * 64 + lane;
+        use_rec = rec_e >= 0;
+        if (!use_rec) k = 0;  // the fill chose "from scratch" for this window (it lies within the first 512 + margin steps)
+    }
 
-    for (int attempt = 0; attempt < 40; ++attempt) {  // bounded: k reaches 0 after <= 32 halvings
+    for (int attempt = 0; attempt < 48; ++attempt) {  // bounded: k reaches 0 after <= 32 halvings
         int tb = t_begin;  // first step to execute
         typename Vec<float, R>::type c;
         typename Vec<int, R>::type s;
         float dprev;
         int sdprev;
-        if (k > 0) {  // restore the exact anti-diagonal state; provenance of these cells is unknown (-1)
+        if (LCK && use_rec) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                c[r] = recp[r * 64];
+                s[r] = -1;
+            }
+            dprev = recp[R * 64];
+            sdprev = -1;
+            tb = t_begin + rec_e;
+        } else if (k > 0) {  // restore the exact anti-diagonal state; provenance of these cells is unknown (-1)
             const float *ckp = a.ck + cd.ck_base +
                                (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job] + (k - 1)) * (ck_planes<R>() * 64) + lane;
 #pragma unroll
@@ -896,10 +1024,12 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
         const int src = (lane & ~(L - 1)) + lq;  // the lane that owns the last query row of this read
         const int q_end = __shfl(cap_end, src), q_st = __shfl(cap_st, src);
         if (!done) {
-            if ((q_end >= 0 && q_st >= 0) || k == 0) {
+            if ((q_end >= 0 && q_st >= 0) || (k == 0 && !(LCK && use_rec))) {
                 res_end = q_end;
                 res_st = q_st;
                 done = true;
+            } else if (LCK && use_rec) {  // the path starts before the saved snapshot: on to the sparse store (k), then 0
+                use_rec = false;
             } else {  // the path starts before this checkpoint: back off (1, 2, 4, ... checkpoints)
                 k = max(0, k - back);
                 back <<= 1;
@@ -935,6 +1065,7 @@ struct FinalizeArgs {
     int32_t *w_job;  // two-pass: winners for the trace kernel
     int32_t *w_end;
     float *w_score;
+    int32_t *w_chunk;  // chunk (task) the winner came from: where the LCK fill left its snapshot
     const int32_t *t_st;  // two-pass, second finalize: start columns [n_reads] then end columns [n_reads] from the trace kernel
     ResultRow *out;       // [n_reads]
     const uint8_t *bad;   // [n_reads] 1: a query value is NaN or +-inf (sdtw_screen_kernel) -> the read is skipped
@@ -942,7 +1073,7 @@ struct FinalizeArgs {
     int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions
 };
 
-template <int MAXR, bool STD>
+template <int MAXR, bool STD, bool LCK = false>
 __global__ void __launch_bounds__(256, MAXR <= 16 ? SFA_TRACE_WAVES : 1) sdtw_trace_kernel(const DpArgs a, int32_t *out_st) {
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (task >= a.n_tasks) return;
@@ -954,7 +1085,7 @@ __global__ void __launch_bounds__(256, MAXR <= 16 ? SFA_TRACE_WAVES : 1) sdtw_tr
     __shared__ int lds_i[4 * kXchWordsPerWave];
 #define SFA_SHAPE(RR, LL)                                                                    \
     case (RR) * 256 + (LL):                                                                  \
-        if constexpr (MAXR >= (RR)) trace_body<RR, LL, STD>(a, cd, tl, out_st, lds_f, lds_i); \
+        if constexpr (MAXR >= (RR)) trace_body<RR, LL, STD, LCK>(a, cd, tl, out_st, lds_f, lds_i); \
         break;
     switch (cd.R * 256 + cd.lanes) {
         SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
@@ -962,7 +1093,7 @@ __global__ void __launch_bounds__(256, MAXR <= 16 ? SFA_TRACE_WAVES : 1) sdtw_tr
         SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
         SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
         default:
-            trace_body<4, 16, STD>(a, cd, tl, out_st, lds_f, lds_i);
+            trace_body<4, 16, STD, LCK>(a, cd, tl, out_st, lds_f, lds_i);
             break;
     }
 #undef SFA_SHAPE
@@ -1053,7 +1184,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     r.mapq = 0;
     r.valid = 0;
     r.pad = 0;
-    int wjob = -1, wend = -1;
+    int wjob = -1, wend = -1, wchunk = 0;
     if (sl >= 0 && !a.bad[i]) {
         const int64_t quad = sl >> 2, slot = sl & 3;
         float best = INFINITY, second = INFINITY;
@@ -1069,6 +1200,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
                 best = b;
                 end = a.p_end[o];
                 job = a.p_job[o];
+                wchunk = ch;
                 if (a.mode == 0) st = a.p_st[o];
             }
         }
@@ -1095,6 +1227,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
         a.w_job[i] = wjob;
         a.w_end[i] = wend;
         a.w_score[i] = r.score;
+        a.w_chunk[i] = wchunk;
     }
     a.out[i] = r;
 }

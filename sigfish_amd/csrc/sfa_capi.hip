@@ -139,6 +139,7 @@ struct sfa_ctx {
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
+    int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
     int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
 
     // reference model (immutable after init)
@@ -160,6 +161,7 @@ struct sfa_ctx {
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
         e_qoff, e_b0, e_b1, e_b2, e_flag, e_qev, e_pflag;
 
+    DevBuf d_bestrec, d_beste, d_gbest, d_wchunk;  // LDS-checkpoint fill: records of the best windows, their step, per-read best score, winning chunk
     DevBuf d_bad, d_badcount;  // sdtw_screen_kernel: per-read flag, number of flagged reads
     PinBuf h_badcount;
     DevBuf d_started;     // counter of the fill's tasks that have begun (IssuePriority)
@@ -229,6 +231,27 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
         SFA_TRACE(4);
     }
 #undef SFA_TRACE
+}
+
+// the variants with rolling checkpoints in LDS (cost-only subsequence DTW, R <= 16)
+void launch_fill_lck(int maxr, const DpArgs &a, hipStream_t st) {
+    const dim3 grid((a.n_tasks + 3) / 4), block(256);
+    if (maxr >= 16)
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<16, false, false, false, true>), grid, block, 0, st, a);
+    else if (maxr >= 8)
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<8, false, false, false, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, false, true>), grid, block, 0, st, a);
+}
+
+void launch_trace_lck(int maxr, const DpArgs &a, int32_t *out_st, hipStream_t st) {
+    const dim3 grid((a.n_tasks + 3) / 4), block(256);
+    if (maxr >= 16)
+        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<16, false, true>), grid, block, 0, st, a, out_st);
+    else if (maxr >= 8)
+        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<8, false, true>), grid, block, 0, st, a, out_st);
+    else
+        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<4, false, true>), grid, block, 0, st, a, out_st);
 }
 
 int resolve_profile(sfa_ctx *c);
@@ -408,6 +431,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.column_segments = c->opt_column_segments;
     pp.segment_warm_windows = c->opt_segment_warm;
     pp.allow_segments = !(c->flag & SFA_DTW) && !c->no_segments_once;
+    pp.lds_ckpt = (c->flag & SFA_DTW) ? 0 : static_cast<int>(c->opt_lds_ckpt);
     std::vector<int32_t> long_reads;  // queries beyond the wave kernels' 2048 events: row strips, after the rest of the batch
     int64_t long_events = 0, long_max = 0;
     for (int32_t i = 0; i < n; ++i)
@@ -450,6 +474,10 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     if ((rc = c->d_pbest.reserve(4 * n_part)) || (rc = c->d_pend.reserve(4 * n_part)) || (rc = c->d_pjob.reserve(4 * n_part)) ||
         (rc = c->d_psecond.reserve(4 * n_part)) || (rc = c->d_wjob.reserve(4 * (size_t)n)) || (rc = c->d_wend.reserve(4 * (size_t)n)) ||
         (rc = c->d_tst.reserve(8 * (size_t)n)) || (rc = c->d_wscore.reserve(4 * (size_t)n)))
+        return rc;
+    if ((rc = c->d_wchunk.reserve(4 * static_cast<size_t>(n)))) return rc;
+    if (plan.lds_ckpt && ((rc = c->d_bestrec.reserve(sizeof(float) * sfa::kLdsCkPlanes * 64 * n_part / 4)) || (rc = c->d_beste.reserve(4 * n_part)) ||
+                          (rc = c->d_gbest.reserve(4 * static_cast<size_t>(n)))))
         return rc;
     if ((rc = c->d_bad.reserve(static_cast<size_t>(n))) || (rc = c->d_badcount.reserve(64)) || (rc = c->h_badcount.reserve(64))) return rc;
     if (plan.single_pass && (rc = c->d_pst.reserve(4 * n_part))) return rc;
@@ -507,6 +535,12 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.verify_planes = verify_planes;
     da.verify = c->d_verify.as<float>();
     da.seg_fail = c->d_segfail.as<int32_t>();
+    da.best_rec = c->d_bestrec.as<float>();
+    da.best_e = c->d_beste.as<int32_t>();
+    da.g_best = c->d_gbest.as<unsigned>();
+    da.w_chunk = c->d_wchunk.as<int32_t>();
+    da.best_planes = sfa::kLdsCkPlanes;
+    da.coarse_every = plan.lds_ckpt ? (1 << (plan.ck_shift - sfa::kLdsCkShift)) : 1;
     da.prio_unit = static_cast<int32_t>(c->opt_prio_unit);
     if ((rc = c->d_started.reserve(64))) return rc;
     da.started = c->d_started.as<unsigned>();
@@ -530,6 +564,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     fz.w_job = da.w_job;
     fz.w_end = da.w_end;
     fz.w_score = da.w_score;
+    fz.w_chunk = da.w_chunk;
     fz.t_st = c->d_tst.as<int32_t>();
     fz.out = d_out;
     fz.bad = c->d_bad.as<uint8_t>();
@@ -545,10 +580,14 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
                        c->d_badcount.as<unsigned>());
     KERNEL_TRY();
     if (n_quads > 0) {
-        if (plan.single_pass)
+        if (plan.lds_ckpt) {
+            HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_gbest.p), 0x7f800000, static_cast<size_t>(n), st));  // +inf: no score seen yet
+            launch_fill_lck(plan.max_R, da, st);
+        } else if (plan.single_pass) {
             launch_fill<true>(plan.max_R, std_dtw, da, st);
-        else
+        } else {
             launch_fill<false>(plan.max_R, std_dtw, da, st);
+        }
         KERNEL_TRY();
         if (plan.n_seg > 1) {  // every hand-over between consecutive segments: assumed state == reached state?
             HIP_TRY(hipMemsetAsync(c->d_segfail.p, 0, 4 * static_cast<size_t>(n_quads), st));
@@ -566,7 +605,10 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         DpArgs ta = da;
         for (int i = 0; i < ta.n_cls; ++i) ta.cls[i].task_base = ta.cls[i].quad_base;  // one task per quad
         ta.n_tasks = n_quads;
-        launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
+        if (plan.lds_ckpt)
+            launch_trace_lck(plan.max_R, ta, c->d_tst.as<int32_t>(), st);
+        else
+            launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
         KERNEL_TRY();
         HIP_TRY(hipEventRecord(c->ev[3], st));
         fz.mode = 2;
@@ -587,6 +629,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     c->prof.cells = (plan.query_events + long_events) * c->total_cols;
     c->prof.ckpt_interval = plan.single_pass ? 0 : (plan.ck_shift ? (1 << plan.ck_shift) : 0);
     c->prof.ckpt_bytes = plan.single_pass ? 0 : static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
+    c->prof.lds_ckpt = plan.lds_ckpt ? 1 : 0;
     c->prof.n_tasks = da.n_tasks;
     c->prof.n_chunks = n_chunks;
     c->prof.n_segments = plan.n_seg;
@@ -651,6 +694,10 @@ extern "C" {
 const char *sfa_last_error(void) { return g_err.c_str(); }
 void sfa_set_error_(const char *msg) { g_err = msg ? msg : ""; }  // for the host-side units of this library
 const char *sfa_version(void) { return SFA_VERSION; }
+#ifndef SFA_BUILD_ID
+#define SFA_BUILD_ID "unknown"
+#endif
+const char *sfa_build_id(void) { return SFA_BUILD_ID; }
 
 }  // extern "C"
 
@@ -834,7 +881,7 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount, &c->d_bestrec, &c->d_beste, &c->d_gbest, &c->d_wchunk})
         b->release();
     c->h_stage.release();
     c->h_out.release();
@@ -887,6 +934,9 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
         c->opt_widen_below = value;
+    } else if (k == "lds_ckpt") {
+        if (value < 0 || value > 2) return fail(SFA_EINVAL, "lds_ckpt must be 0 (off), 1 (where shapes and batch size suit) or 2 (wherever the shapes allow)");
+        c->opt_lds_ckpt = value;
     } else if (k == "prio_unit") {
         if (value < 0 || value > (1 << 28)) return fail(SFA_EINVAL, "prio_unit must be 0 (off) .. 2^28");
         c->opt_prio_unit = value;

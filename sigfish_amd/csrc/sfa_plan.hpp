@@ -61,6 +61,7 @@ struct PlanParams {
     int64_t column_segments = 0;    // 0 = auto (small batches of the 64-lane shapes), 1 = off, N = N segments per job
     int64_t segment_warm_windows = 4;  // windows (query lengths) a segment starts before its own first one
     bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory) and single pass
+    int lds_ckpt = 0;               // 1: rolling checkpoints in LDS + sparse HBM checkpoints (sdtw_kernels.hpp, LdsCkpt) where the shapes allow and the batch size suits; 2: wherever the shapes allow
     bool skip_long = false;         // true: reads of more than kMaxQuery events are left out (the caller runs them in row strips, sdtw_strips.hpp)
 };
 
@@ -73,6 +74,7 @@ struct BatchPlan {
     int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, widening = 1, ck_shift = 0, trace_margin = 0;
     int32_t n_seg = 1, warm_windows = 4;  // column segments per job (sdtw_kernels.hpp, sweep_segment)
     bool single_pass = false;
+    bool lds_ckpt = false;  // the fill keeps its snapshots in LDS; ck_shift is then the interval of the sparse HBM store
     int64_t ck_floats = 0, query_events = 0;
     std::vector<int32_t> order;         // [4*max(n_quads,1)] read per (quad,slot) or -1
     std::vector<int32_t> quad_qlen;     // [max(n_quads,1)]
@@ -89,6 +91,7 @@ struct BatchPlan {
         n_quads = 0; n_chunks = 1; max_R = 4; max_lanes = 16; widening = 1; ck_shift = 0; trace_margin = 0;
         n_seg = 1; warm_windows = 4;
         single_pass = false;
+        lds_ckpt = false;
         ck_floats = 0; query_events = 0;
         classes.clear();
     }
@@ -244,8 +247,19 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // checkpoint interval
     p.job_ck_off.assign(n_jobs + 1, 0);
     p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + p.max_lanes);
+    // LDS checkpoints: every shape of the batch must hold its state in 17 planes (R <= 16), one sweep per (quad, job); the
+    // margin is capped so that the snapshot pass 2 wants for a window is one of the last two (LdsCkpt::save):
+    // 512 >= window length + margin + 3
+    p.lds_ckpt = pp.lds_ckpt && !pp.single_pass && pp.ckpt_interval == 0 && p.max_R <= 16 && p.n_seg == 1 && n_quads > 0 && maxq <= 256;
+    {   // the LDS buffers cap the fill at four waves per SIMD instead of six: a batch whose tasks are all resident at six
+        // but not at four would need a second round (measured: 8 192 reads 7.35 -> 7.65 ms); everything else gains
+        // (16 384 reads 13.7 -> 13.4 ms, 100 000 reads 74.6 -> 73.5 ms)
+        const int64_t tasks = static_cast<int64_t>(n_quads) * p.n_chunks;
+        if (pp.lds_ckpt < 2 && tasks > 4 * pp.n_sims && tasks <= 6 * pp.n_sims) p.lds_ckpt = false;
+    }
+    if (p.lds_ckpt) p.trace_margin = std::min<int32_t>(p.trace_margin, 512 - maxq - 3);
     if (!pp.single_pass && n_quads > 0) {
-        int shift = 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length)
+        int shift = p.lds_ckpt ? 15 : 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length); sparse store: 32768
         if (pp.ckpt_interval > 0) {
             shift = 0;
             while ((1ll << shift) < pp.ckpt_interval) ++shift;

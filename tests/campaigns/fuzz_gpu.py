@@ -28,6 +28,8 @@ def main():
         quant = bool(rng.integers(0, 2))
         nref = int(rng.integers(1, 13))
         lens = [int(x) for x in rng.choice([1, 2, 3, 5, 17, 64, 250, 251, 500, 999, 1024, 1500, 3000, 5000], size=nref)]
+        if rng.integers(0, 12) == 0:  # a strand long enough for the sparse HBM checkpoints behind the LDS ones (every 32768 steps)
+            lens[int(rng.integers(0, nref))] = int(rng.choice([33000, 40000, 70000]))
 
         def arr(n):
             return (rng.integers(-8, 9, n) / 4).astype(np.float32) if quant else rng.normal(size=n).astype(np.float32)
@@ -54,6 +56,10 @@ def main():
             opts["trace_margin"] = int(rng.choice([0, 3, 50, 300]))
         if rng.integers(0, 5) == 0:
             opts["single_pass"] = 1
+        if rng.integers(0, 3) == 0:
+            opts["lds_ckpt"] = 0  # every snapshot to HBM (default: rolling in LDS where the shapes allow)
+        if rng.integers(0, 3) == 0:
+            opts["prio_unit"] = int(rng.choice([0, 64, 700]))
         opts["lane_widening"] = int(rng.choice([0, 1, 1, 2, 4]))  # small batches widen by themselves; pin the other shapes too
         if rng.integers(0, 2):  # column segments (small batches): forced counts and short warm-ups exercise the hand-over check
             opts["column_segments"] = int(rng.choice([1, 2, 3, 8, 16]))

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_json_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "3000", "--cpu-seconds", "2"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "3000", "--cpu-seconds", "2", "--e2e-reads", "2000"],
                        capture_output=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
@@ -32,3 +32,11 @@ def test_bench_json_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb.get("parity_on_sample") is True
+    # the end-to-end leg (raw BLOW5 -> PAF through the command line, files generated in the run): extra keys, never `value`
+    e2e = d["end_to_end"]
+    assert "error" not in e2e, e2e
+    for key in ("uncompressed_K4096", "uncompressed_K512", "compressed_K4096", "compressed_K512"):
+        assert e2e[key] > 0, key
+    assert e2e["reads"] == 2000 and e2e["unit"] == "reads/s"
+    assert d["library_build"] and d["rccl_world_size"] == 1
+    assert d["roofline"]["traffic"] is None  # a 3000-read batch was never profiled: no stale counters are quoted

@@ -30,7 +30,11 @@ def assert_rows_equal(got, want):
 # the two-pass default, the single-pass variant, a configuration that forces dense checkpoints + back-off (all three
 # pinned to the throughput shapes, 16 lanes per read), the small-batch shapes (rows per lane / 2 and / 4), and what the
 # planner picks by itself for these small batches
+# "hbm_ckpt": every snapshot of pass 1 in HBM (the round-1 scheme; the default now keeps them in LDS where the shapes allow);
+# "lds_backoff": LDS checkpoints with no head start at all, so that pass 2 must back off to the sparse store / the strand start
 MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "lane_widening": 1},
+         "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1}, "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2},
+         "lds_wide4_backoff": {"trace_margin": 0, "lane_widening": 4, "column_segments": 1, "lds_ckpt": 2},
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
          "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
          "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""End-to-end wall of the command line: raw BLOW5 -> PAF through `sigfish-amd dtw` (SURVEY.md 8d "plus end-to-end wall").
+
+    python tools/e2e_bench.py [--reads 400000] [--threads 16] [--ks 4096,512]
+
+Generates two files with tools/make_blow5.py from the reference's own DNA fixture replicated --reads/5 times --
+uncompressed, and zlib records + svb-zd signals (what real files look like) -- runs the command line on each at every -K
+(whole process: start-up, reference upload, file mapping, host stages, GPU stages, output) and prints one JSON object.
+bench.py calls measure() for the `end_to_end` key of its line (never `value`)."""
+import argparse
+import itertools
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "sigfish_amd", "bin", "sigfish-amd")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
+    d = keep_dir or tempfile.mkdtemp(prefix="sfa_e2e_")
+    out = {"unit": "reads/s", "reads": 0, "host_threads": threads,
+           "what": "raw BLOW5 -> PAF through `sigfish-amd dtw` (process start to exit), reference's DNA fixture replicated, nCoV reference"}
+    try:
+        lv = np.fromfile(os.path.join(GOLD, "models", "syn6.f32"), np.float32)
+        model = os.path.join(d, "syn6.model")
+        with open(model, "w") as f:
+            f.write("#k\t6\nkmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+            for kmer, v in zip(itertools.product("ACGT", repeat=6), lv):
+                f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
+        copies = max(reads // 5, 1)
+        want_head = open(os.path.join(GOLD, "cases", "dna_default.out")).read().splitlines()
+        for kind, flags in (("uncompressed", []), ("compressed", ["--compress"])):
+            path = os.path.join(d, kind + ".blow5")
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
+                            "--copies", str(copies), "--jobs", str(min(threads, 16)), *flags], check=True, capture_output=True)
+            out[kind + "_file_MB"] = round(os.path.getsize(path) / 1e6, 1)
+            for k in ks:
+                paf = os.path.join(d, "out.paf")
+                t0 = time.perf_counter()
+                with open(paf, "wb") as fo:
+                    r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", str(k), "-B", "2G", "--verbose", "0", *extra,
+                                        os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path], stdout=fo, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(f"sigfish-amd dtw failed on the {kind} file at -K {k}: {r.stderr.decode()[-500:]}")
+                n = 0
+                ok = True
+                with open(paf) as fi:
+                    for i, line in enumerate(fi):
+                        n += 1
+                        if i < 5:  # first copy of the fixture's reads: same rows as the fixture, read ids carry the copy suffix
+                            a, b = line.split("\t"), want_head[i].split("\t")
+                            ok = ok and a[0] == b[0] + "_0" and a[1:] == b[1:]
+                if n != copies * 5 or not ok:
+                    raise RuntimeError(f"end-to-end output differs from the fixture on the {kind} file at -K {k} ({n} rows)")
+                out["reads"] = n
+                out[f"{kind}_K{k}"] = round(n / dt, 1)
+            os.remove(path)
+        out["parity"] = "row count and the first five rows (= the reference's PAF for the fixture) checked in every run"
+    finally:
+        if not keep_dir:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=400_000)
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--ks", default="4096,512")
+    ap.add_argument("extra", nargs="*")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.reads, a.threads, tuple(int(k) for k in a.ks.split(",")), extra=a.extra)))

@@ -36,6 +36,21 @@ def svb_zd(raw):
     return struct.pack("<I", n) + keys.tobytes() + b[mask].tobytes()
 
 
+def _records(args):
+    """records of copies [c0, c1) as one bytes object (worker of --jobs)"""
+    reads, sig, c0, c1, rec_zlib, sig_svb = args
+    out = []
+    for c in range(c0, c1):
+        for (rid, meta, raw), body in zip(reads, sig):
+            name = f"{rid}_{c}".encode()
+            payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, meta["digitisation"], meta["offset"], meta["range"],
+                                                                      meta["sampling_rate"], len(body) if sig_svb else len(raw)) + body
+            if rec_zlib:
+                payload = zlib.compress(payload, 6)
+            out.append(struct.pack("<Q", len(payload)) + payload)
+    return b"".join(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
@@ -44,6 +59,7 @@ def main():
     ap.add_argument("--compress", action="store_true", help="zlib records + svb-zd signals (as real BLOW5 files)")
     ap.add_argument("--record-press", choices=["none", "zlib"], default=None, help="record compression alone")
     ap.add_argument("--signal-press", choices=["none", "svb-zd"], default=None, help="signal compression alone")
+    ap.add_argument("--jobs", type=int, default=1, help="worker processes (zlib of every record is what takes the time)")
     a = ap.parse_args()
     f = S.Blow5File(a.src)
     reads = list(f)
@@ -59,15 +75,17 @@ def main():
     with open(a.dst, "wb") as out:
         out.write(hdr)
         sig = [svb_zd(raw) if sig_svb else raw.tobytes() for _, _, raw in reads]
-        for c in range(a.copies):
-            for (rid, meta, raw), body in zip(reads, sig):
-                name = f"{rid}_{c}".encode()
-                payload = struct.pack("<H", len(name)) + name + struct.pack("<I4dQ", 0, meta["digitisation"], meta["offset"], meta["range"],
-                                                                          meta["sampling_rate"], len(body) if sig_svb else len(raw)) + body
-                if rec_zlib:
-                    payload = zlib.compress(payload, 6)
-                out.write(struct.pack("<Q", len(payload)) + payload)
-                n += 1
+        step = max(1, min(2000, a.copies // max(4 * a.jobs, 1) or 1))
+        tasks = [(reads, sig, c0, min(c0 + step, a.copies), rec_zlib, sig_svb) for c0 in range(0, a.copies, step)]
+        if a.jobs > 1 and len(tasks) > 1:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(a.jobs) as pool:
+                for blob in pool.imap(_records, tasks):  # in order: read ids stay in file order
+                    out.write(blob)
+        else:
+            for t in tasks:
+                out.write(_records(t))
+        n = a.copies * len(reads)
         out.write(b"5WOLB")
     print(f"{a.dst}: {n} reads, {os.path.getsize(a.dst) / 1e6:.1f} MB")
 

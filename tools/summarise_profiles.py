@@ -42,6 +42,10 @@ def main(d, tag):
                 vals = [per[k][c][i][0] for i in keep]
                 durs = [per[k][c][i][1] for i in keep]
                 rows.append((k, c, len(keep), sum(vals) / len(vals), sum(durs) / len(durs)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import sigfish_amd
+    with open(os.path.join(d, f"{tag}_build_id.txt"), "w") as f:  # bench.py quotes these counters only for this build
+        f.write(sigfish_amd.build_id() + "\n")
     with open(os.path.join(d, f"{tag}_pmc_summary.csv"), "w") as f:
         f.write("kernel,counter,dispatches,mean_value_per_dispatch,mean_duration_ms_in_that_pass\n")
         for k, c, n, v, t in rows:
