@@ -100,7 +100,10 @@ typedef struct {
     /* reads of the batch whose query holds a NaN or +-inf event.  The reference aborts on such a read (assert in update_aln,
      * src/sigfish.c:611); here they are skipped: their rows come back with valid = 0. */
     int64_t non_finite_reads;
-    int64_t lds_ckpt;      /* 1: the fill kept its rolling checkpoints in LDS (ckpt_interval is then the sparse HBM store's) */
+    double decode_ms;      /* sfa_align_blow5 only: record decompression (inflate), field parsing and signal decoding on the device */
+    int64_t blow5_fallbacks; /* batches of this context handed to the host reader because the device declined a record */
+    int64_t lds_ckpt;      /* 1: the fill kept its rolling checkpoints in LDS (ckpt_interval is then the sparse HBM store's);
+                              2: and pass 2 ran inside the fill launch (fill_ms covers both, trace_ms is 0) */
 } sfa_profile_t;
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */
@@ -245,6 +248,35 @@ int sfa_align_raw(sfa_ctx_t *ctx, const int16_t *raw, const int64_t *raw_off, co
  * (pass it with qstart = 0, qend = the window length).  query_events may be NULL (then identical to sfa_align_raw). */
 int sfa_align_raw_ex(sfa_ctx_t *ctx, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n_reads,
                   int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_event_t *query_events);
+
+/* ---- BLOW5 records in, result rows out: the record decoder on the GPU as well ------------------------------ */
+
+/* What the output writer needs from a record besides its alignment (slow5_rec_t fields, slow5lib/include/slow5/slow5.h). */
+typedef struct {
+    char read_id[128];     /* NUL terminated */
+    int32_t id_len;
+    int32_t pad;
+    int64_t n_samples;     /* len_raw_signal */
+    double digitisation, offset, range;
+    int64_t record_bytes;  /* on-disk size of the record (the reference's -B accounting, src/sigfish.c:304) */
+} sfa_read_head_t;
+
+/* load_db()'s records straight to the device (src/sigfish.c:274-314 hands them to parse_single, 317-328, on host threads):
+ * records: the BLOW5 records of a batch back to back WITHOUT their u64 size prefixes, rec_off[n+1] their offsets;
+ * record_zlib / signal_svb: the file's compression methods (record_press == zlib, signal_press == svb-zd).  Every record
+ * is inflated (own DEFLATE decoder, one lane per record), its primary fields are parsed and its signal decoded
+ * (StreamVByte zig-zag deltas, one wave per record) on the device; the path of sfa_align_raw_ex continues from there.
+ * heads[n] receives the fields the output needs.  A record the device decoder declines (malformed, longer read id than
+ * sfa_read_head_t holds, inflating to more than 4x its size + 4 KB) sends the batch through the library's host reader
+ * instead -- same results, counted in sfa_profile_t.blow5_fallbacks.  Other arguments as for sfa_align_raw_ex. */
+int sfa_align_blow5(sfa_ctx_t *ctx, const uint8_t *records, const int64_t *rec_off, int32_t n_reads, int32_t record_zlib,
+                    int32_t signal_svb, int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info,
+                    sfa_read_head_t *heads, sfa_event_t *query_events);
+
+/* The device-side DEFLATE decoder on its own (tests): n zlib streams in[in_off[i]..in_off[i+1]) -> out[out_off[i]..),
+ * out_len[i] = bytes produced or -1 (malformed, or larger than its slot).  Single-device context. */
+int sfa_inflate_zlib_device(sfa_ctx_t *ctx, const uint8_t *in, const int64_t *in_off, int32_t n, uint8_t *out, const int64_t *out_off,
+                            int32_t *out_len);
 
 /* Page-locked host memory for the buffers handed to sfa_align_raw / sfa_align_batch (uploads from pageable memory
  * run at a fraction of the PCIe rate).  Plain malloc-style pair; NULL on failure. */

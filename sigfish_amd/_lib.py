@@ -26,7 +26,7 @@ class SfaProfile(C.Structure):
                 ("total_ms", C.c_double), ("cells", C.c_int64), ("fill_launches", C.c_int64),
                 ("ckpt_interval", C.c_int64), ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64),
                 ("n_chunks", C.c_int64), ("n_segments", C.c_int64), ("segment_reruns", C.c_int64),
-                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64), ("lds_ckpt", C.c_int64)]
+                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64), ("decode_ms", C.c_double), ("blow5_fallbacks", C.c_int64), ("lds_ckpt", C.c_int64)]
 
 
 class SfaPlanInfo(C.Structure):
@@ -41,12 +41,17 @@ class SfaQueryInfo(C.Structure):
                 ("end_raw_idx", C.c_uint64), ("status", C.c_int32), ("pad", C.c_int32)]
 
 
+class SfaReadHead(C.Structure):
+    _fields_ = [("read_id", C.c_char * 128), ("id_len", C.c_int32), ("pad", C.c_int32), ("n_samples", C.c_int64),
+                ("digitisation", C.c_double), ("offset", C.c_double), ("range", C.c_double), ("record_bytes", C.c_int64)]
+
+
 class SfaEvent(C.Structure):
     _fields_ = [("start", C.c_uint64), ("length", C.c_float), ("mean", C.c_float), ("stdv", C.c_float)]
 
 
 # every symbol include/sigfish_amd.h declares (checked by tests/test_capi_host.py::test_library_exports_every_declared_symbol)
-SYMBOLS = ["sfa_init", "sfa_init_devices", "sfa_n_devices", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
+SYMBOLS = ["sfa_init", "sfa_init_devices", "sfa_n_devices", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_align_blow5", "sfa_inflate_zlib_device", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_build_id", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_r2qevent_map", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
            "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close", "sfa_inflate_zlib", "sfa_device_memory"]
@@ -74,6 +79,8 @@ def load():
     L.sfa_align_events.argtypes = [vp, C.POINTER(C.POINTER(SfaEvent)), i64p, i64p, i64p, C.c_int32, vp]
     L.sfa_align_raw.argtypes = [vp, C.POINTER(C.c_int16), i64p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, vp, vp]
     L.sfa_align_raw_ex.argtypes = [vp, C.POINTER(C.c_int16), i64p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
+    L.sfa_align_blow5.argtypes = [vp, vp, i64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]
+    L.sfa_inflate_zlib_device.argtypes = [vp, vp, i64p, C.c_int32, vp, i64p, i32p]
     L.sfa_pinned_alloc.argtypes = [C.c_size_t]
     L.sfa_pinned_alloc.restype = vp
     L.sfa_pinned_free.argtypes = [vp]

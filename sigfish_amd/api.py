@@ -248,6 +248,39 @@ class Aligner:
                                         qev.ctypes.data_as(C.c_void_p) if return_events else None), "sfa_align_raw_ex")
         return (rows, info, qev) if return_events else (rows, info)
 
+    def align_blow5(self, records, rec_off, record_zlib, signal_svb, prefix_size=50, query_size=250, return_events=False):
+        """load_db's records straight to the device: `records` = the BLOW5 records of a batch back to back (bytes / uint8 array,
+        without their size prefixes), rec_off int64[n+1].  -> (rows, info, heads[, query events])"""
+        rec = np.frombuffer(records, np.uint8) if isinstance(records, (bytes, bytearray, memoryview)) else np.ascontiguousarray(records, np.uint8)
+        ro = np.ascontiguousarray(rec_off, np.int64)
+        n = len(ro) - 1
+        rows = np.zeros(n, RESULT_DTYPE)
+        info = np.zeros(n, QUERY_INFO_DTYPE)
+        heads = (_lib.SfaReadHead * max(n, 1))()
+        qev = np.zeros((n, query_size), EVENT_DTYPE) if return_events else None
+        if rec.size == 0:
+            rec = np.zeros(1, np.uint8)
+        _check(self._L.sfa_align_blow5(self._h, rec.ctypes.data_as(C.c_void_p), ro.ctypes.data_as(_lib.i64p), n, int(bool(record_zlib)),
+                                       int(bool(signal_svb)), prefix_size, query_size, rows.ctypes.data_as(C.c_void_p),
+                                       info.ctypes.data_as(C.c_void_p), C.cast(heads, C.c_void_p),
+                                       qev.ctypes.data_as(C.c_void_p) if return_events else None), "sfa_align_blow5")
+        hs = [dict(read_id=heads[i].read_id.decode(), n_samples=heads[i].n_samples, digitisation=heads[i].digitisation,
+                   offset=heads[i].offset, range=heads[i].range, record_bytes=heads[i].record_bytes) for i in range(n)]
+        return (rows, info, hs, qev) if return_events else (rows, info, hs)
+
+    def inflate_device(self, streams, cap_factor=4, cap_extra=4096):
+        """The device-side DEFLATE decoder alone: list of zlib streams -> list of bytes (None where the decoder declined)."""
+        n = len(streams)
+        in_off = np.concatenate([[0], np.cumsum([len(x) for x in streams])]).astype(np.int64)
+        blob = np.frombuffer(b"".join(streams) + b"\0" * 8, np.uint8)
+        out_off = np.concatenate([[0], np.cumsum([len(x) * cap_factor + cap_extra for x in streams])]).astype(np.int64)
+        out = np.zeros(int(out_off[-1]) + 8, np.uint8)
+        lens = np.zeros(max(n, 1), np.int32)
+        _check(self._L.sfa_inflate_zlib_device(self._h, blob.ctypes.data_as(C.c_void_p), in_off.ctypes.data_as(_lib.i64p), n,
+                                               out.ctypes.data_as(C.c_void_p), out_off.ctypes.data_as(_lib.i64p),
+                                               lens.ctypes.data_as(_lib.i32p)), "sfa_inflate_zlib_device")
+        return [None if lens[i] < 0 else out[out_off[i]:out_off[i] + lens[i]].tobytes() for i in range(n)]
+
     def sync(self):
         _check(self._L.sfa_sync(self._h), "sfa_sync")
 

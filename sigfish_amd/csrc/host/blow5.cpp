@@ -278,9 +278,13 @@ bool Blow5Reader::parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::
 }
 
 bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const {
+    return parse_blow5_record(mem, size, record_press_ == 1, signal_press_ == 1, rec, err);
+}
+
+bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int signal_svb, Blow5Record *rec, std::string *err) {
     rec->record_bytes = size;
     const uint8_t *p = mem, *end = p + size;
-    if (record_press_ == 1) {
+    if (record_zlib) {
         const uint8_t *inflated = nullptr;  // this thread's buffer, valid until its next record
         size_t inflated_len = 0;
         if (!inflate_all(mem, size, &inflated, &inflated_len)) {
@@ -300,7 +304,7 @@ bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::
              take(p, end, &rec->range) && take(p, end, &rec->sampling_rate) && take(p, end, &len);
     }
     if (ok) {
-        if (signal_press_ == 0) {
+        if (!signal_svb) {
             ok = len <= static_cast<uint64_t>(end - p) / 2;  // (not len * 2: a corrupt length must not wrap around)
             if (ok) {
                 rec->raw.resize(len);

@@ -26,6 +26,10 @@ struct Blow5Record {
     uint64_t record_bytes = 0;  // on-disk payload size (the reference's -B accounting, sigfish.c:304)
 };
 
+// One record's bytes -> fields + samples, given the file's compression methods (what Blow5Reader::parse does; free-standing
+// for callers that hold record bytes without a reader, e.g. the fallback of the device-side decoder)
+bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int signal_svb, Blow5Record *rec, std::string *err);
+
 class Blow5Reader {
   public:
     ~Blow5Reader() { close(); }
@@ -44,6 +48,8 @@ class Blow5Reader {
     // first value (read group 0) of a header attribute, or nullptr (slow5_hdr_get(attr, 0, hdr))
     const char *attr(const std::string &key) const;
     uint32_t num_read_groups() const { return n_groups_; }
+    bool records_zlib() const { return record_press_ == 1; }  // the whole record is a zlib stream
+    bool signal_svb() const { return signal_press_ == 1; }    // the signal is StreamVByte of zig-zag deltas
     const std::string &error() const { return err_; }
 
   private:

@@ -42,6 +42,7 @@ struct Opt {
     int verbosity = 4;
     std::vector<int> devices{0};  // --device 0,1,...: batches go to the devices in turn
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
+    bool host_parse = false;   // --host-parse: records are decompressed and parsed on host threads instead of the GPU
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     const char *model_file = nullptr;
     const char *pore = nullptr;
@@ -95,7 +96,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --host-parse               decompress and parse the records on host threads instead of the GPU\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -223,7 +224,7 @@ static int dtw_run(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -275,6 +276,7 @@ static int dtw_run(int argc, char **argv) {
                 break;
             }
             case 14: o.host_events = true; break;
+            case 16: o.host_parse = true; break;
             case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }
@@ -390,12 +392,20 @@ static int dtw_run(int argc, char **argv) {
         std::vector<double> scaling;
         std::vector<sfa_query_info_t> info;
         std::vector<sfa_event_t> qev;  // [n][query] event tables of the query windows (SAM with device-side events)
+        // device-side record decoding: the records' bytes as they are in the file, back to back, page-locked
+        uint8_t *rec_bytes = nullptr;
+        size_t rec_cap = 0;
+        std::vector<int64_t> rec_off;
+        std::vector<sfa_read_head_t> heads;
         int32_t n = 0;
         int64_t bytes = 0;
     };
     // events on the GPU unless the RNA auto prefix is asked for (adaptor/poly-A detection stays on the host); for SAM the
     // event tables of the query windows come back from the device with the rows
     const bool gpu_events = !o.host_events && o.prefix >= 0;
+    // ... and so do the records themselves: inflate, field parsing and signal decoding run on the device (sfa_align_blow5); the
+    // host only frames the records and copies their bytes into page-locked staging
+    const bool gpu_parse = gpu_events && !o.host_parse;
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);
@@ -412,7 +422,14 @@ static int dtw_run(int argc, char **argv) {
         const int32_t n = sl.n;
         std::vector<sfa_result_t> &rows = sl.rows;
         const double a = realtime();
-        if (gpu_events) {
+        if (gpu_parse) {
+            sl.info.resize(n);
+            sl.heads.resize(n);
+            if (sam) sl.qev.resize(static_cast<size_t>(n) * o.query);
+            if (n > 0 && sfa_align_blow5(ctx, sl.rec_bytes, sl.rec_off.data(), n, reader.records_zlib(), reader.signal_svb(), o.prefix, o.query,
+                                         rows.data(), sl.info.data(), sl.heads.data(), sam ? sl.qev.data() : nullptr) != SFA_OK)
+                die(std::string("alignment failed: ") + sfa_last_error());
+        } else if (gpu_events) {
             sl.info.resize(n);
             if (sam) sl.qev.resize(static_cast<size_t>(n) * o.query);
             if (n > 0 && sfa_align_raw_ex(ctx, sl.raw, sl.raw_off.data(), sl.scaling.data(), n, o.prefix, o.query, rows.data(),
@@ -427,6 +444,7 @@ static int dtw_run(int argc, char **argv) {
         t_dtw += realtime() - a;
         if (prf) {
             if (gpu_events) {  // events and normalisation ran on the device, inside the same call
+                t_parse += pr.decode_ms * 1e-3;  // ... and so did parse_single's work, when the records went up as they are
                 t_events += pr.events_ms * 1e-3;
                 t_norm += pr.normalise_ms * 1e-3;
                 t_dtw_stage += pr.total_ms * 1e-3;
@@ -459,11 +477,12 @@ static int dtw_run(int argc, char **argv) {
                 const int64_t qs = gpu_events ? 0 : r.qstart, qe = gpu_events ? sl.info[i].qend - sl.info[i].qstart : r.qend;
                 const float *y = row.strand == '+' ? fwd[row.rid].data() : rev[row.rid].data();
                 std::string buf(1 << 16, '\0');
-                int len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), ev, qs, qe, y,
+                const char *rid = gpu_parse ? sl.heads[i].read_id : r.rec.read_id.c_str();
+                int len = sfa_sam_row(&buf[0], buf.size(), &row, rid, contigs[row.rid].name.c_str(), ev, qs, qe, y,
                                       ref_len[row.rid], ref_off[row.rid], o.flag);
                 if (len == SFA_ERANGE) {  // very long ss strings (full-reference alignments)
                     buf.assign(1 << 22, '\0');
-                    len = sfa_sam_row(&buf[0], buf.size(), &row, r.rec.read_id.c_str(), contigs[row.rid].name.c_str(), ev, qs, qe, y,
+                    len = sfa_sam_row(&buf[0], buf.size(), &row, rid, contigs[row.rid].name.c_str(), ev, qs, qe, y,
                                       ref_len[row.rid], ref_off[row.rid], o.flag);
                 }
                 if (len > 0) sam[i].assign(buf.data(), len);
@@ -486,8 +505,10 @@ static int dtw_run(int argc, char **argv) {
                     end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
                     qsize = static_cast<uint64_t>((r.qend - 1) - r.qstart);
                 }
-                const int len = sfa_paf_row(&line[0], line.size(), &rows[i], r.rec.read_id.c_str(), contigs[rows[i].rid].name.c_str(),
-                                            start_raw, end_raw, qsize, r.rec.raw.size(), static_cast<uint64_t>(seq_len[rows[i].rid]));
+                const char *rid = gpu_parse ? sl.heads[i].read_id : r.rec.read_id.c_str();
+                const uint64_t n_raw = gpu_parse ? static_cast<uint64_t>(sl.heads[i].n_samples) : r.rec.raw.size();
+                const int len = sfa_paf_row(&line[0], line.size(), &rows[i], rid, contigs[rows[i].rid].name.c_str(),
+                                            start_raw, end_raw, qsize, n_raw, static_cast<uint64_t>(seq_len[rows[i].rid]));
                 if (len < 0) die("PAF line too long");
                 fwrite(line.data(), 1, len, stdout);
             }
@@ -550,7 +571,24 @@ static int dtw_run(int argc, char **argv) {
                 r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), static_cast<int64_t>(r.rec.raw.size()), pa.data(), o.prefix, o.query,
                                                    o.flag, o.pore_flag, &r.qstart, &r.qend, &r.status);
         };
-        if (!prf) {  // one fan-out per batch, every read through all its host stages (work_per_single_read, src/sigfish.c:995-1001)
+        if (gpu_parse) {  // nothing to parse here: the records go to the device as they are
+            double b = realtime();
+            sl.rec_off.resize(n + 1);
+            sl.rec_off[0] = 0;
+            for (int32_t i = 0; i < n; ++i) sl.rec_off[i + 1] = sl.rec_off[i] + static_cast<int64_t>(batch[i].view_size);
+            const size_t need = static_cast<size_t>(sl.rec_off[n]) + 64;
+            if (need > sl.rec_cap) {
+                sfa_pinned_free(sl.rec_bytes);
+                sl.rec_cap = need + need / 4;
+                sl.rec_bytes = static_cast<uint8_t *>(sfa_pinned_alloc(sl.rec_cap));
+                if (!sl.rec_bytes) die(std::string("cannot allocate the record staging buffer: ") + sfa_last_error());
+            }
+            pool.run(n, [&](int64_t i) {
+                const uint8_t *src = batch[i].view ? batch[i].view : batch[i].mem.data();
+                memcpy(sl.rec_bytes + sl.rec_off[i], src, batch[i].view_size);
+            });
+            t_parse += realtime() - b;
+        } else if (!prf) {  // one fan-out per batch, every read through all its host stages (work_per_single_read, src/sigfish.c:995-1001)
             pool.run(n, [&](int64_t i) {
                 parse_one(i);
                 if (bad || gpu_events || batch[i].rec.raw.empty()) return;
@@ -577,7 +615,7 @@ static int dtw_run(int argc, char **argv) {
             }
         }
         if (bad) die("error parsing a BLOW5 record");
-        if (gpu_events) {  // pack the samples of the batch for one upload
+        if (gpu_events && !gpu_parse) {  // pack the samples of the batch for one upload
             sl.raw_off.resize(n + 1);
             sl.scaling.resize(3 * static_cast<size_t>(n));
             sl.raw_off[0] = 0;
@@ -632,7 +670,10 @@ static int dtw_run(int argc, char **argv) {
         if (gpu_pending[b % n_ctx].valid()) gpu_pending[b % n_ctx].get();
         output(slots[b % n_slots]);
     }
-    for (Slot &sl : slots) sfa_pinned_free(sl.raw);
+    for (Slot &sl : slots) {
+        sfa_pinned_free(sl.raw);
+        sfa_pinned_free(sl.rec_bytes);
+    }
     if (o.verbosity >= 3 && prf) {  // the reference's lines, src/dtw_main.c:331-343
         fprintf(stderr, "[dtw_main] total entries: %ld\tprefix fail: %ld\tignored: %ld\ttoo short: %ld", (long)total, (long)prefix_fail, (long)ignored, (long)too_short);
         fprintf(stderr, "\n[dtw_main] total bytes: %.1f M", sum_bytes / 1e6);

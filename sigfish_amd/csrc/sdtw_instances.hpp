@@ -18,6 +18,7 @@ SFA_FOR_MAXR(SFA_TRACE_DECL, true)
 // LDS-checkpoint variants (cost-only subsequence DTW, R <= 16): own translation unit sdtw_inst_lck16.hip
 #define SFA_LCK_DECL(MR)                                                                               \
     extern template __global__ void sdtw_fill_kernel<MR, false, false, false, true>(const DpArgs);    \
+    extern template __global__ void sdtw_fill_kernel<MR, false, false, false, true, true>(const DpArgs); \
     extern template __global__ void sdtw_trace_kernel<MR, false, true>(const DpArgs, int32_t *);
 SFA_LCK_DECL(4) SFA_LCK_DECL(8) SFA_LCK_DECL(16)
 }  // namespace sfa

@@ -124,6 +124,17 @@ struct DpArgs {
     int32_t *w_chunk;
     int32_t best_planes;   // planes per record (R of the largest class + 1)
     int32_t coarse_every;  // every coarse_every-th LDS snapshot also goes to the HBM checkpoint store (ck_shift = 9 + log2 of it)
+    // fused launch (FUSED kernels): waves claim tickets; tickets < n_tasks are fill tasks, ticket n_tasks + q is pass 2 of quad q,
+    // which waits until quad_done[q] == n_chunks.  Rows are written by the pass-2 waves (tables as FinalizeArgs).
+    unsigned *ticket;
+    int32_t *quad_done;
+    int32_t n_quads_total;
+    const int32_t *job_contig;
+    const int8_t *job_strand;
+    const int32_t *ref_len;
+    const int32_t *ref_st_offset;
+    const uint8_t *bad;
+    struct ResultRow *out;
     // longest-remaining-first issue priority in the tail of the launch (see IssuePriority): columns per priority step,
     // 0 = off; `started` counts the tasks that have begun (zeroed before the launch)
     int32_t prio_unit;
@@ -253,7 +264,7 @@ struct IssuePriority {
     int countdown;  // windows until the next look at the counter; < 0: the tail has begun
     const unsigned *started;
     unsigned n_tasks;
-    __device__ __forceinline__ void start(int u, int rem, unsigned *started_ctr, unsigned total) {
+    __device__ __forceinline__ void start(int u, int rem, unsigned *started_ctr, unsigned total, bool count_me = true) {
         unit = u;
         remaining = rem;
         next_drop = 0x7fffffff;
@@ -264,7 +275,7 @@ struct IssuePriority {
             // top level until the tail is seen: a wave left at the default (lowest) level next to waves that already lowered
             // theirs step by step from 3 would starve, never reach its next look at the counter, and finish alone
             set_issue_priority(3);
-            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(started_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (count_me && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(started_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __device__ __forceinline__ void update(int col) {  // at a window boundary, col columns into the current job
@@ -579,7 +590,7 @@ __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp,
     }
 }
 
-template <int R, int L, bool TRACK, bool STD, bool LCK = false>
+template <int R, int L, bool TRACK, bool STD, bool LCK = false, bool FUSED = false>
 __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i,
                                           float *lds_ck = nullptr) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
@@ -618,7 +629,8 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         const bool on = !TRACK && a.prio_unit > 0;
         if (on)
             for (int job = jb; job < je; ++job) cols += a.job_len[job];
-        pr.start(on ? a.prio_unit : 0, cols, a.started, static_cast<unsigned>(a.n_tasks));
+        // fused launch: the ticket counter already says how many tasks have begun
+        pr.start(on ? a.prio_unit : 0, cols, FUSED ? a.ticket : a.started, static_cast<unsigned>(a.n_tasks), !FUSED);
     }
     LdsCkpt lck;
     if (LCK) {
@@ -645,6 +657,11 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         a.p_end[o] = top.end;
         a.p_job[o] = top.job;
         if (TRACK) a.p_st[o] = top.st;
+    }
+    if (FUSED) {  // partial results and best-window records of this task are complete: publish, then count the quad's task in
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_fetch_add(a.quad_done + quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        set_issue_priority(0);
     }
 #ifdef SFA_TASK_TIMES
     if (a.task_times && lane == 0) {
@@ -840,11 +857,28 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 // compiled in, so a batch without long queries does not pay the long variant's register budget.
 // SEG: the column-segment variant (cost-only sDTW, small batches) is its own kernel, so that the throughput kernel's code
 // is not touched by it.
+// pass 2 of one quad inside the fill launch (FUSED kernels; defined behind the trace code)
+// (not inlined: its register needs -- 128 VGPRs and some spills -- then stay its own business instead of leaning on the
+// allocation of the fill loops it shares the kernel with; and the arguments BY VALUE: a reference would force the kernel to
+// keep a copy of its kernarg block in scratch, and the fill loops would then read `a.xyz` from there, per lane, instead of
+// from scalar registers -- measured as a scratch load in every block of four steps)
+template <int MAXR>
+__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs a, const int quad, float *lds_f, int *lds_i);
+
 // LCK: rolling checkpoints in LDS (LdsCkpt) -- two snapshots of 17 planes per wave, 34 KB per block, four blocks per CU.
-template <int MAXR, bool TRACK, bool STD, bool SEG = false, bool LCK = false>
+// FUSED (with LCK): pass 2 rides in the same launch.  Waves claim TICKETS from a counter instead of deriving their task from
+// blockIdx: tickets below n_tasks are the fill tasks, in the usual order; ticket n_tasks + q is pass 2 of quad q, which waits
+// until every fill task of that quad has signalled completion, merges their partial results (what sdtw_finalize_kernel
+// does between the launches otherwise), recovers the start columns and writes the quad's rows.  Because a ticket is only
+// claimed by a wave that is running, everything a pass-2 wave waits for is held by a resident wave: the wait cannot
+// deadlock whatever order the hardware starts blocks in.  The point: when the fill's last tasks drain, SIMDs go idle one
+// after the other for ~2 ms; the pass-2 tickets are claimed exactly then, so pass 2 (3 ms as its own
+// launch) runs in that slack, at the lowest issue priority, and two launches + the kernel boundaries disappear.
+template <int MAXR, bool TRACK, bool STD, bool SEG = false, bool LCK = false, bool FUSED = false>
 __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES)))) sdtw_fill_kernel(const DpArgs a) {
     static_assert(!SEG || (!TRACK && !STD), "segments: cost-only subsequence DTW");
     static_assert(!LCK || (!TRACK && !STD && !SEG && MAXR <= 16), "LDS checkpoints: cost-only subsequence DTW, R <= 16");
+    static_assert(!FUSED || LCK, "the fused launch is built on the LDS-checkpoint fill");
     // blockIdx -> task.  Blocks are dealt to the 8 XCDs round-robin, so with the identity every XCD sees every class and
     // every chunk of the job list evenly -- what this kernel wants: the reference arrays (hundreds of KB to a few MB) stay
     // resident in every XCD's L2 anyway, whereas the classes differ in speed.  Measured (A/B builds, fill ms): identity
@@ -863,22 +897,32 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
         lblk = lo + xcd_contiguous_block(blockIdx.x - lo, hi - lo);
     }
 #endif
-    const int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
+    int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[(TRACK || FUSED) ? 4 * kXchWordsPerWave : 1];
+    __shared__ float lds_ck[LCK ? 4 * 2 * kLdsCkPlanes * 64 : 1];
+    if (FUSED) {
+        unsigned t = 0;
+        if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        task = __builtin_amdgcn_readfirstlane(t);
+        if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
+            const int quad = task - a.n_tasks;
+            if (quad < a.n_quads_total) fused_trace_dispatch<MAXR>(a, quad, lds_f, lds_i);  // ONE call site: one argument copy on the stack
+            return;
+        }
+    }
     if (task >= a.n_tasks) return;  // wave-uniform
     int ci = 0;
     while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
     const ClassDesc cd = a.cls[ci];
     const int tl = task - cd.task_base;
-    __shared__ float lds_f[4 * kXchWordsPerWave];
-    __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
-    __shared__ float lds_ck[LCK ? 4 * 2 * kLdsCkPlanes * 64 : 1];
 #define SFA_SHAPE(RR, LL)                                                                    \
     case (RR) * 256 + (LL):                                                                  \
         if constexpr (MAXR >= (RR)) {                                                        \
             if constexpr (SEG)                                                               \
                 fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */   \
             else                                                                             \
-                fill_body<RR, LL, TRACK, STD, LCK>(a, cd, tl, lds_f, lds_i, lds_ck);         \
+                fill_body<RR, LL, TRACK, STD, LCK, FUSED>(a, cd, tl, lds_f, lds_i, lds_ck);  \
         }                                                                                    \
         break;
     switch (cd.R * 256 + cd.lanes) {
@@ -899,9 +943,42 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
 // ---------------------------------------------------------------------------------------------------------
 struct ResultRow;  // below
 
+// the winner of a read as pass 2 needs it (per lane: the value of the lane's read)
+struct Winner {
+    int job;     // -1: nothing to trace
+    int ws;      // first column of the winning window
+    float best;  // the winning score
+    int chunk;   // LCK: the task whose record holds the snapshot
+};
+
+template <int R, int L, bool STD, bool LCK = false>
+__device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, const int quad_local, const Winner w, float *lds_f, int *lds_i,
+                                           int &res_st, int &res_end);
+
 template <int R, int L, bool STD, bool LCK = false>
 __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st, float *lds_f,
                                            int *lds_i) {
+    const int quad = cd.quad_base + quad_local;
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / L;
+    const int read = a.order[quad * 4 + slot];
+    Winner w;
+    w.job = (read >= 0) ? a.w_job[read] : -1;
+    w.ws = (read >= 0) ? a.w_end[read] : 0;
+    w.best = (read >= 0) ? a.w_score[read] : 0.0f;
+    w.chunk = (LCK && read >= 0) ? a.w_chunk[read] : 0;
+    int res_st, res_end;
+    trace_core<R, L, STD, LCK>(a, cd, quad_local, w, lds_f, lds_i, res_st, res_end);
+    const int qlen = a.quad_qlen[quad];
+    if ((lane & (L - 1)) == (qlen - 1) / R && read >= 0) {
+        out_st[read] = res_st;
+        out_st[a.n_reads_total + read] = res_end;
+    }
+}
+
+template <int R, int L, bool STD, bool LCK>
+__device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, const int quad_local, const Winner w, float *lds_f, int *lds_i,
+                                           int &res_st, int &res_end) {
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
     const int g = lane & (L - 1);
@@ -918,9 +995,9 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     Exchange xc;
     xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
 
-    int job = (read >= 0) ? a.w_job[read] : -1;
-    const int ws = (read >= 0) ? a.w_end[read] : 0;  // first column of the winning window
-    const float best = (read >= 0) ? a.w_score[read] : 0.0f;
+    int job = (read >= 0) ? w.job : -1;
+    const int ws = (read >= 0) ? w.ws : 0;  // first column of the winning window
+    const float best = (read >= 0) ? w.best : 0.0f;
     bool done = !(read >= 0 && job >= 0 && ws >= 0);
     job = done ? 0 : job;
     const int rlen = a.job_len[job];
@@ -941,7 +1018,8 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
         k = k < nck ? k : nck;
     }
     int back = 1;
-    int res_st = -1, res_end = -1;
+    res_st = -1;
+    res_end = -1;
     const unsigned long long owner = __ballot(g == lq);  // the lanes that own a last query row
     // LCK: the first attempt restores the snapshot the fill saved for the winning window (the record of the read's winning
     // chunk); only if the path began before it do the sparse HBM checkpoints (k, as computed above with their interval) come in
@@ -949,7 +1027,7 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     const float *recp = nullptr;
     int rec_e = -1;
     if (LCK && !done) {
-        const int64_t task = static_cast<int64_t>(quad) * a.n_chunks + a.w_chunk[read];
+        const int64_t task = static_cast<int64_t>(quad) * a.n_chunks + w.chunk;
         rec_e = a.best_e[task * 4 + slot];
         recp = a.best_rec + task * a.best_planes * 64 + lane;
         use_rec = rec_e >= 0;
@@ -1037,10 +1115,6 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
         }
         if (__all(done)) break;
     }
-    if (g == lq && read >= 0) {
-        out_st[read] = res_st;
-        out_st[a.n_reads_total + read] = res_end;
-    }
 }
 
 // One result row per read, POD mirror of sfa_result_t (include/sigfish_amd.h).
@@ -1070,7 +1144,8 @@ struct FinalizeArgs {
     ResultRow *out;       // [n_reads]
     const uint8_t *bad;   // [n_reads] 1: a query value is NaN or +-inf (sdtw_screen_kernel) -> the read is skipped
     int32_t n_reads, n_chunks;
-    int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions
+    int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions;
+                   // 3: fused launch -> rows of the reads that are in no quad (skipped), the rest is written by its pass-2 waves
 };
 
 template <int MAXR, bool STD, bool LCK = false>
@@ -1110,6 +1185,105 @@ __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
         q = static_cast<int>(r);
     if (q > 60) q = 60;
     return static_cast<uint8_t>(q);
+}
+
+template <int R, int L>
+__device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDesc cd, const int quad_local, float *lds_f, int *lds_i) {
+    const int quad = cd.quad_base + quad_local;
+    const int lane = threadIdx.x & 63;
+    const int g = lane & (L - 1);
+    const int slot = lane / L;
+    // every fill task of the quad must have published its results (they hold lower tickets: running or finished)
+    if (lane == 0) {
+        while (__hip_atomic_load(a.quad_done + quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_chunks) __builtin_amdgcn_s_sleep(32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    const int qlen = a.quad_qlen[quad];
+    const int lq = (qlen - 1) / R;
+    const int read = a.order[quad * 4 + slot];
+    const bool owner = (g == lq) && read >= 0;
+    // merge of the chunks' partial top-2 in processing order (sdtw_finalize_kernel, mode 1), one lane per read
+    ResultRow r;
+    r.rid = -1;
+    r.pos_st = -1;
+    r.pos_end = -1;
+    r.score = INFINITY;
+    r.score2 = INFINITY;
+    r.strand = 0;
+    r.mapq = 0;
+    r.valid = 0;
+    r.pad = 0;
+    Winner w;
+    w.job = -1;
+    w.ws = -1;
+    w.best = 0.0f;
+    w.chunk = 0;
+    if (owner && !a.bad[read]) {
+        float best = INFINITY, second = INFINITY;
+        int end = -1, job = -1, chunk = 0;
+        for (int ch = 0; ch < a.n_chunks; ++ch) {  // a later chunk wins ties
+            const int64_t o = (static_cast<int64_t>(quad) * a.n_chunks + ch) * 4 + slot;
+            const float b = a.p_best[o], s2 = a.p_second[o];
+            const float hi = fmaxf(best, b);
+            const float lo2 = fminf(second, s2);
+            const bool take = !(b > best);
+            second = fminf(hi, lo2);
+            if (take) {
+                best = b;
+                end = a.p_end[o];
+                job = a.p_job[o];
+                chunk = ch;
+            }
+        }
+        r.valid = 1;
+        r.score = best;
+        r.score2 = second;
+        if (job >= 0) {
+            r.rid = a.job_contig[job];
+            r.strand = a.job_strand[job];
+            r.mapq = mapq_from_scores(best, second);
+            w.job = job;
+            w.ws = end;
+            w.best = best;
+            w.chunk = chunk;
+        }
+    }
+    const int src = (lane & ~(L - 1)) + lq;  // the read's owner lane
+    w.job = __shfl(w.job, src);
+    w.ws = __shfl(w.ws, src);
+    w.best = __shfl(w.best, src);
+    w.chunk = __shfl(w.chunk, src);
+    int res_st, res_end;
+    trace_core<R, L, false, true>(a, cd, quad_local, w, lds_f, lds_i, res_st, res_end);
+    if (owner) {
+        if (r.rid >= 0) {  // src/sigfish.c:971-975
+            const int rl = a.ref_len[r.rid], off = a.ref_st_offset[r.rid];
+            r.pos_st = ((r.strand == '+') ? res_st : rl - res_end) + off;
+            r.pos_end = ((r.strand == '+') ? res_end : rl - res_st) + off;
+        }
+        a.out[read] = r;
+    }
+}
+
+template <int MAXR>
+__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs a, const int quad, float *lds_f, int *lds_i) {
+    int ci = 0;
+    while (ci + 1 < a.n_cls && quad >= a.cls[ci + 1].quad_base) ++ci;
+    const ClassDesc cd = a.cls[ci];
+    const int ql = quad - cd.quad_base;
+#define SFA_TSHAPE(RR, LL)                                                               \
+    case (RR) * 256 + (LL):                                                              \
+        if constexpr (MAXR >= (RR)) fused_trace_task<RR, LL>(a, cd, ql, lds_f, lds_i);    \
+        break;
+    switch (cd.R * 256 + cd.lanes) {
+        SFA_TSHAPE(16, 64) SFA_TSHAPE(16, 32) SFA_TSHAPE(16, 16)
+        SFA_TSHAPE(8, 64) SFA_TSHAPE(8, 32) SFA_TSHAPE(8, 16)
+        SFA_TSHAPE(4, 64) SFA_TSHAPE(4, 32) SFA_TSHAPE(4, 16)
+        default:
+            break;
+    }
+#undef SFA_TSHAPE
 }
 
 #ifdef SFA_DEFINE_FINALIZE_KERNEL  // plain (non-template) kernels: defined in exactly one translation unit
@@ -1161,6 +1335,21 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_reads) return;
     const int sl = a.slot_of_read[i];
+    if (a.mode == 3) {  // fused launch: its pass-2 waves write the rows of every read they handle; the others are skipped reads
+        if (sl >= 0) return;
+        ResultRow r;
+        r.rid = -1;
+        r.pos_st = -1;
+        r.pos_end = -1;
+        r.score = INFINITY;
+        r.score2 = INFINITY;
+        r.strand = 0;
+        r.mapq = 0;
+        r.valid = 0;
+        r.pad = 0;
+        a.out[i] = r;
+        return;
+    }
     if (a.mode == 2) {  // positions from the traced start column
         if (sl < 0) return;
         ResultRow r = a.out[i];

@@ -22,6 +22,8 @@
 #define SFA_DEFINE_FINALIZE_KERNEL
 #include "sdtw_kernels.hpp"
 #include "events_kernels.hpp"
+#include "blow5_kernels.hpp"
+#include "host/blow5.hpp"
 #include "sdtw_instances.hpp"
 #include "sdtw_strips.hpp"
 #include "sfa_plan.hpp"
@@ -139,6 +141,7 @@ struct sfa_ctx {
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
+    int64_t opt_fused_trace = 1;             // 1: with LDS checkpoints, pass 2 rides in the fill launch as trailing tickets (fills the drain)
     int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
     int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
 
@@ -161,6 +164,12 @@ struct sfa_ctx {
     DevBuf e_raw, e_rawoff, e_scale, e_sum, e_sumsq, e_t1, e_t2, e_evoff, e_evstart, e_evlen, e_evmean, e_evstdv, e_nev, e_qstart,
         e_qoff, e_b0, e_b1, e_b2, e_flag, e_qev, e_pflag;
 
+    DevBuf b_in, b_inoff, b_out, b_outoff, b_len, b_head, b_bad;  // sfa_align_blow5: record bytes, inflated payloads, field rows
+    PinBuf h_head;
+    hipEvent_t bev[2] = {nullptr, nullptr};  // record decoding start / end
+    bool bev_pending = false;
+    int64_t blow5_fallbacks = 0;  // batches handed to the host reader because the device declined a record
+    DevBuf d_ticket, d_quaddone;  // fused launch: ticket counter, completed fill tasks per quad
     DevBuf d_bestrec, d_beste, d_gbest, d_wchunk;  // LDS-checkpoint fill: records of the best windows, their step, per-read best score, winning chunk
     DevBuf d_bad, d_badcount;  // sdtw_screen_kernel: per-read flag, number of flagged reads
     PinBuf h_badcount;
@@ -242,6 +251,16 @@ void launch_fill_lck(int maxr, const DpArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<8, false, false, false, true>), grid, block, 0, st, a);
     else
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, false, true>), grid, block, 0, st, a);
+}
+
+void launch_fill_fused(int maxr, const DpArgs &a, hipStream_t st) {  // fill tasks + one pass-2 ticket per quad
+    const dim3 grid((a.n_tasks + 3) / 4 + (a.n_quads_total + 3) / 4), block(256);
+    if (maxr >= 16)
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<16, false, false, false, true, true>), grid, block, 0, st, a);
+    else if (maxr >= 8)
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<8, false, false, false, true, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, false, true, true>), grid, block, 0, st, a);
 }
 
 void launch_trace_lck(int maxr, const DpArgs &a, int32_t *out_st, hipStream_t st) {
@@ -476,6 +495,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         (rc = c->d_tst.reserve(8 * (size_t)n)) || (rc = c->d_wscore.reserve(4 * (size_t)n)))
         return rc;
     if ((rc = c->d_wchunk.reserve(4 * static_cast<size_t>(n)))) return rc;
+    const bool fused = plan.lds_ckpt && c->opt_fused_trace;
+    if (fused && ((rc = c->d_ticket.reserve(64)) || (rc = c->d_quaddone.reserve(4 * static_cast<size_t>(std::max(n_quads, 1)))))) return rc;
     if (plan.lds_ckpt && ((rc = c->d_bestrec.reserve(sizeof(float) * sfa::kLdsCkPlanes * 64 * n_part / 4)) || (rc = c->d_beste.reserve(4 * n_part)) ||
                           (rc = c->d_gbest.reserve(4 * static_cast<size_t>(n)))))
         return rc;
@@ -541,6 +562,15 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.w_chunk = c->d_wchunk.as<int32_t>();
     da.best_planes = sfa::kLdsCkPlanes;
     da.coarse_every = plan.lds_ckpt ? (1 << (plan.ck_shift - sfa::kLdsCkShift)) : 1;
+    da.ticket = c->d_ticket.as<unsigned>();
+    da.quad_done = c->d_quaddone.as<int32_t>();
+    da.n_quads_total = n_quads;
+    da.job_contig = c->d_job_contig.as<int32_t>();
+    da.job_strand = c->d_job_strand.as<int8_t>();
+    da.ref_len = c->d_ref_len.as<int32_t>();
+    da.ref_st_offset = c->d_ref_off.as<int32_t>();
+    da.bad = c->d_bad.as<uint8_t>();
+    da.out = d_out;
     da.prio_unit = static_cast<int32_t>(c->opt_prio_unit);
     if ((rc = c->d_started.reserve(64))) return rc;
     da.started = c->d_started.as<unsigned>();
@@ -582,7 +612,16 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     if (n_quads > 0) {
         if (plan.lds_ckpt) {
             HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_gbest.p), 0x7f800000, static_cast<size_t>(n), st));  // +inf: no score seen yet
-            launch_fill_lck(plan.max_R, da, st);
+            if (fused) {
+                HIP_TRY(hipMemsetAsync(c->d_ticket.p, 0, 4, st));
+                HIP_TRY(hipMemsetAsync(c->d_quaddone.p, 0, 4 * static_cast<size_t>(n_quads), st));
+                fz.mode = 3;  // rows of the reads in no quad; every other row is written by the launch's pass-2 waves
+                hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
+                KERNEL_TRY();
+                launch_fill_fused(plan.max_R, da, st);
+            } else {
+                launch_fill_lck(plan.max_R, da, st);
+            }
         } else if (plan.single_pass) {
             launch_fill<true>(plan.max_R, std_dtw, da, st);
         } else {
@@ -597,6 +636,10 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         }
     }
     HIP_TRY(hipEventRecord(c->ev[1], st));
+    if (fused && n_quads > 0) {  // nothing left to do: rows are complete
+        HIP_TRY(hipEventRecord(c->ev[2], st));
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+    } else {
     fz.mode = plan.single_pass ? 0 : 1;
     hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
     KERNEL_TRY();
@@ -617,6 +660,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     } else {
         HIP_TRY(hipEventRecord(c->ev[3], st));
     }
+    }
     c->prof.fill_launches = n_quads > 0 ? 1 : 0;
     c->long_pending = !long_reads.empty();
     if (c->long_pending) {
@@ -629,7 +673,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     c->prof.cells = (plan.query_events + long_events) * c->total_cols;
     c->prof.ckpt_interval = plan.single_pass ? 0 : (plan.ck_shift ? (1 << plan.ck_shift) : 0);
     c->prof.ckpt_bytes = plan.single_pass ? 0 : static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
-    c->prof.lds_ckpt = plan.lds_ckpt ? 1 : 0;
+    c->prof.lds_ckpt = plan.lds_ckpt ? (fused ? 2 : 1) : 0;
     c->prof.n_tasks = da.n_tasks;
     c->prof.n_chunks = n_chunks;
     c->prof.n_segments = plan.n_seg;
@@ -670,6 +714,14 @@ int resolve_profile(sfa_ctx *c) {
         c->long_pending = false;
     }
     c->prof.events_ms = c->prof.normalise_ms = 0;
+    c->prof.decode_ms = 0;
+    c->prof.blow5_fallbacks = c->blow5_fallbacks;
+    if (c->bev_pending) {
+        float d1 = 0;
+        HIP_TRY(hipEventElapsedTime(&d1, c->bev[0], c->bev[1]));
+        c->prof.decode_ms = d1;
+        c->bev_pending = false;
+    }
     if (c->eev_pending) {
         float e1 = 0, e2 = 0;
         HIP_TRY(hipEventElapsedTime(&e1, c->eev[0], c->eev[1]));
@@ -782,6 +834,8 @@ static int create_context(sfa_ctx **out, const HostRef &h, uint32_t flag, int de
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     for (auto &e : c->eev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
+    for (auto &e : c->bev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     int rc;
     const size_t ref_bytes = sizeof(float) * h.packed.size();
     if ((rc = c->d_ref.reserve(ref_bytes)) || (rc = c->d_job_off.reserve(sizeof(int64_t) * c->n_jobs)) ||
@@ -881,7 +935,7 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount, &c->d_bestrec, &c->d_beste, &c->d_gbest, &c->d_wchunk})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount, &c->d_bestrec, &c->d_beste, &c->d_gbest, &c->d_wchunk, &c->d_ticket, &c->d_quaddone, &c->b_in, &c->b_inoff, &c->b_out, &c->b_outoff, &c->b_len, &c->b_head, &c->b_bad})
         b->release();
     c->h_stage.release();
     c->h_out.release();
@@ -889,6 +943,9 @@ void sfa_destroy(sfa_ctx_t *c) {
     c->h_flags.release();
     c->h_long.release();
     c->h_badcount.release();
+    c->h_head.release();
+    for (auto &e : c->bev)
+        if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->eev)
@@ -934,6 +991,8 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
         c->opt_widen_below = value;
+    } else if (k == "fused_trace") {
+        c->opt_fused_trace = value != 0;
     } else if (k == "lds_ckpt") {
         if (value < 0 || value > 2) return fail(SFA_EINVAL, "lds_ckpt must be 0 (off), 1 (where shapes and batch size suit) or 2 (wherever the shapes allow)");
         c->opt_lds_ckpt = value;
@@ -1058,9 +1117,18 @@ int sfa_align_raw(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, cons
     return sfa_align_raw_ex(c, raw, raw_off, scaling, n, prefix_size, query_size, rows, info, nullptr);
 }
 
+static int align_raw_impl(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n, int32_t prefix_size,
+                          int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_event_t *query_events);
+
 int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n, int32_t prefix_size,
                      int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_event_t *query_events) {
     if (!c || n < 0 || (n > 0 && (!raw || !raw_off || !scaling || !rows || !info))) return fail(SFA_EINVAL, "sfa_align_raw: bad argument");
+    return align_raw_impl(c, raw, raw_off, scaling, n, prefix_size, query_size, rows, info, query_events);
+}
+
+// raw == nullptr: the samples are already in c->e_raw (decoded on the device, sfa_align_blow5), laid out by raw_off
+static int align_raw_impl(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, const double *scaling, int32_t n, int32_t prefix_size,
+                          int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_event_t *query_events) {
     if (prefix_size < 0) return fail(SFA_EINVAL, "sfa_align_raw: automatic query start (-p -1) needs the host stages");
     if (query_size <= 0) return fail(SFA_EINVAL, "sfa_align_raw: query_size must be positive");
     if (n == 0) return SFA_OK;
@@ -1072,13 +1140,14 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
             if (a == b) return static_cast<int>(SFA_OK);
             std::vector<int64_t> off(b - a + 1);  // the shard's sample offsets start at 0
             for (int32_t i = a; i <= b; ++i) off[i - a] = raw_off[i] - raw_off[a];
+            if (!raw) return fail(SFA_EINVAL, "sfa_align_raw: device-resident samples need a single-device context");
             return sfa_align_raw_ex(c->shards[r], raw + raw_off[a], off.data(), scaling + 3 * static_cast<size_t>(a), b - a, prefix_size,
                                     query_size, rows + a, info + a,
                                     query_events ? query_events + static_cast<size_t>(a) * static_cast<size_t>(query_size) : nullptr);
         });
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (raw) HIP_TRY(hipStreamSynchronize(c->stream));  // (device-resident samples: their decoder is still in flight on this stream)
     const int64_t total = raw_off[n] - raw_off[0];
     if (total < 0 || raw_off[0] != 0) return fail(SFA_EINVAL, "sfa_align_raw: raw_off must start at 0 and be monotone");
     const bool rna = (c->flag & SFA_RNA) != 0;
@@ -1107,7 +1176,7 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
         (rc = c->e_nev.reserve(4 * (size_t)n)) || (rc = c->e_qstart.reserve(8 * (size_t)n)) || (rc = c->e_qoff.reserve(8 * (size_t)(n + 1))) ||
         (rc = c->e_flag.reserve(4 * (size_t)n)) || (rc = c->e_pflag.reserve(4 * (size_t)n)) || (rc = c->e_b0.reserve(4 * (size_t)n)) || (rc = c->e_b1.reserve(4 * (size_t)n)) || (rc = c->e_b2.reserve(4 * (size_t)n)))
         return rc;
-    HIP_TRY(hipMemcpyAsync(c->e_raw.p, raw, 2 * (size_t)total, hipMemcpyHostToDevice, st));
+    if (raw) HIP_TRY(hipMemcpyAsync(c->e_raw.p, raw, 2 * (size_t)total, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->e_scale.p, scale.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->e_evoff.p, ev_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
@@ -1239,6 +1308,171 @@ int sfa_align_raw_ex(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_off, c
     return resolve_profile(c);
 }
 
+// BLOW5 records in, result rows out: records are decompressed and parsed on the device (blow5_kernels.hpp), then the path of
+// sfa_align_raw continues on the samples where they already are.
+int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off, int32_t n, int32_t record_zlib, int32_t signal_svb,
+                    int32_t prefix_size, int32_t query_size, sfa_result_t *rows, sfa_query_info_t *info, sfa_read_head_t *heads,
+                    sfa_event_t *query_events) {
+    if (!c || n < 0 || (n > 0 && (!records || !rec_off || !rows || !info || !heads))) return fail(SFA_EINVAL, "sfa_align_blow5: bad argument");
+    if (prefix_size < 0) return fail(SFA_EINVAL, "sfa_align_blow5: automatic query start (-p -1) needs the host stages");
+    if (query_size <= 0) return fail(SFA_EINVAL, "sfa_align_blow5: query_size must be positive");
+    if (n == 0) return SFA_OK;
+    if (!c->shards.empty()) {
+        std::vector<int32_t> lo;
+        shard_ranges(n, c->shards.size(), &lo);
+        return for_each_shard(c, [&](size_t r) {
+            const int32_t a = lo[r], b = lo[r + 1];
+            if (a == b) return static_cast<int>(SFA_OK);
+            std::vector<int64_t> off(b - a + 1);
+            for (int32_t i = a; i <= b; ++i) off[i - a] = rec_off[i] - rec_off[a];
+            return sfa_align_blow5(c->shards[r], records + rec_off[a], off.data(), b - a, record_zlib, signal_svb, prefix_size, query_size,
+                                   rows + a, info + a, heads + a,
+                                   query_events ? query_events + static_cast<size_t>(a) * static_cast<size_t>(query_size) : nullptr);
+        });
+    }
+    if (rec_off[0] != 0) return fail(SFA_EINVAL, "sfa_align_blow5: rec_off must start at 0");
+    for (int32_t i = 0; i < n; ++i)
+        if (rec_off[i + 1] < rec_off[i]) return fail(SFA_EINVAL, "sfa_align_blow5: rec_off not monotone at record %d", i);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipStream_t st = c->stream;
+    const int64_t in_bytes = rec_off[n];
+    int rc;
+    // a compressed record inflates into a slot of 4x its size + 4 KB (svb-zd signals deflate by ~1.5x; a record that needs
+    // more is handed to the host reader with the rest of the batch)
+    std::vector<int64_t> slot(n + 1);
+    slot[0] = 0;
+    for (int32_t i = 0; i < n; ++i) slot[i + 1] = slot[i] + (record_zlib ? (((rec_off[i + 1] - rec_off[i]) * 4 + 4096 + 15) & ~int64_t(15)) : 0);
+    if ((rc = c->b_in.reserve(static_cast<size_t>(in_bytes) + 64)) || (rc = c->b_inoff.reserve(8 * static_cast<size_t>(n + 1))) ||
+        (rc = c->b_head.reserve(static_cast<size_t>(n) * sfa::kBlow5HeadBytes)) || (rc = c->h_head.reserve(static_cast<size_t>(n) * sfa::kBlow5HeadBytes + 8 * static_cast<size_t>(n))) ||
+        (rc = c->b_len.reserve(4 * static_cast<size_t>(n))) || (rc = c->b_bad.reserve(4 * static_cast<size_t>(n))))
+        return rc;
+    if (record_zlib && ((rc = c->b_out.reserve(static_cast<size_t>(slot[n]) + 64)) || (rc = c->b_outoff.reserve(8 * static_cast<size_t>(n + 1))))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->b_in.p, records, static_cast<size_t>(in_bytes), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->b_inoff.p, rec_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->b_bad.p, 0, 4 * static_cast<size_t>(n), st));
+    HIP_TRY(hipEventRecord(c->bev[0], st));
+    sfa::FieldsArgs fa{};
+    if (record_zlib) {
+        HIP_TRY(hipMemcpyAsync(c->b_outoff.p, slot.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+        sfa::InflateArgs ia{c->b_in.as<uint8_t>(), c->b_inoff.as<int64_t>(), c->b_out.as<uint8_t>(), c->b_outoff.as<int64_t>(), c->b_len.as<int32_t>(), n};
+        hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + sfa::kInfLanes - 1) / sfa::kInfLanes), dim3(64), 0, st, ia);
+        KERNEL_TRY();
+        fa.payload = c->b_out.as<uint8_t>();
+        fa.payload_off = c->b_outoff.as<int64_t>();
+        fa.payload_len = c->b_len.as<int32_t>();
+    } else {
+        fa.payload = c->b_in.as<uint8_t>();
+        fa.payload_off = c->b_inoff.as<int64_t>();
+        fa.payload_len = nullptr;
+    }
+    fa.head = c->b_head.as<uint8_t>();
+    fa.signal_svb = signal_svb ? 1 : 0;
+    fa.n = n;
+    hipLaunchKernelGGL(sfa::blow5_fields_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
+    KERNEL_TRY();
+    uint8_t *hh = c->h_head.as<uint8_t>();
+    HIP_TRY(hipMemcpyAsync(hh, c->b_head.p, static_cast<size_t>(n) * sfa::kBlow5HeadBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // the fields of every record; anything the device declined sends the whole batch to the host reader
+    std::vector<int64_t> raw_off(n + 1);
+    std::vector<double> scaling(3 * static_cast<size_t>(n));
+    raw_off[0] = 0;
+    bool fallback = false;
+    for (int32_t i = 0; i < n && !fallback; ++i) {
+        const uint8_t *h = hh + static_cast<size_t>(i) * sfa::kBlow5HeadBytes;
+        int32_t status, id_len;
+        int64_t ns;
+        memcpy(&status, h, 4);
+        memcpy(&id_len, h + 4, 4);
+        memcpy(&ns, h + 8, 8);
+        if (status != 0 || id_len < 0 || id_len > static_cast<int32_t>(sizeof(heads[i].read_id)) - 1 || ns < 0) {
+            fallback = true;
+            break;
+        }
+        memcpy(heads[i].read_id, h + 56, id_len);
+        heads[i].read_id[id_len] = 0;
+        heads[i].id_len = id_len;
+        heads[i].n_samples = ns;
+        memcpy(&heads[i].digitisation, h + 16, 8);
+        memcpy(&heads[i].offset, h + 24, 8);
+        memcpy(&heads[i].range, h + 32, 8);
+        heads[i].record_bytes = rec_off[i + 1] - rec_off[i];
+        scaling[3 * i] = heads[i].digitisation;
+        scaling[3 * i + 1] = heads[i].offset;
+        scaling[3 * i + 2] = heads[i].range;
+        raw_off[i + 1] = raw_off[i] + ns;
+    }
+    if (!fallback) {
+        const int64_t total = raw_off[n];
+        if ((rc = c->e_raw.reserve(2 * static_cast<size_t>(std::max<int64_t>(total, 1)))) || (rc = c->e_rawoff.reserve(8 * static_cast<size_t>(n + 1)))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+        sfa::SvbArgs sa{fa.payload, fa.payload_off, c->b_head.as<uint8_t>(), c->e_rawoff.as<int64_t>(), c->e_raw.as<int16_t>(), c->b_bad.as<int32_t>(),
+                        signal_svb ? 1 : 0, n};
+        hipLaunchKernelGGL(sfa::blow5_svb_kernel, dim3((n + 3) / 4), dim3(256), 0, st, sa);
+        KERNEL_TRY();
+        int32_t *bad = reinterpret_cast<int32_t *>(hh + static_cast<size_t>(n) * sfa::kBlow5HeadBytes);
+        HIP_TRY(hipMemcpyAsync(bad, c->b_bad.p, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->bev[1], st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int32_t i = 0; i < n && !fallback; ++i) fallback = bad[i] != 0;
+        if (!fallback) {
+            c->bev_pending = true;
+            return align_raw_impl(c, nullptr, raw_off.data(), scaling.data(), n, prefix_size, query_size, rows, info, query_events);
+        }
+    }
+    // host reader for the whole batch (own inflate / zlib, SSSE3 StreamVByte): malformed records are reported from there
+    c->blow5_fallbacks++;
+    std::vector<int16_t> raw;
+    raw_off[0] = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        sfa::Blow5Record rec;
+        std::string err;
+        if (!sfa::parse_blow5_record(records + rec_off[i], static_cast<size_t>(rec_off[i + 1] - rec_off[i]), record_zlib, signal_svb, &rec, &err))
+            return fail(SFA_EINVAL, "sfa_align_blow5: record %d: %s", i, err.c_str());
+        if (rec.read_id.size() > sizeof(heads[i].read_id) - 1) return fail(SFA_ERANGE, "sfa_align_blow5: record %d: read id of %zu bytes", i, rec.read_id.size());
+        memcpy(heads[i].read_id, rec.read_id.c_str(), rec.read_id.size() + 1);
+        heads[i].id_len = static_cast<int32_t>(rec.read_id.size());
+        heads[i].n_samples = static_cast<int64_t>(rec.raw.size());
+        heads[i].digitisation = rec.digitisation;
+        heads[i].offset = rec.offset;
+        heads[i].range = rec.range;
+        heads[i].record_bytes = rec_off[i + 1] - rec_off[i];
+        scaling[3 * i] = rec.digitisation;
+        scaling[3 * i + 1] = rec.offset;
+        scaling[3 * i + 2] = rec.range;
+        raw.insert(raw.end(), rec.raw.begin(), rec.raw.end());
+        raw_off[i + 1] = static_cast<int64_t>(raw.size());
+    }
+    if (raw.empty()) raw.push_back(0);
+    return align_raw_impl(c, raw.data(), raw_off.data(), scaling.data(), n, prefix_size, query_size, rows, info, query_events);
+}
+
+// (testing hook of the device-side inflate alone: n zlib streams in, their bytes out; see include/sigfish_amd.h)
+int sfa_inflate_zlib_device(sfa_ctx_t *c, const uint8_t *in, const int64_t *in_off, int32_t n, uint8_t *out, const int64_t *out_off, int32_t *out_len) {
+    if (!c || !c->shards.empty() || n < 0 || (n > 0 && (!in || !in_off || !out || !out_off || !out_len)))
+        return fail(SFA_EINVAL, "sfa_inflate_zlib_device: bad argument (single-device context needed)");
+    if (n == 0) return SFA_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    hipStream_t st = c->stream;
+    int rc;
+    if ((rc = c->b_in.reserve(static_cast<size_t>(in_off[n]) + 64)) || (rc = c->b_inoff.reserve(8 * static_cast<size_t>(n + 1))) ||
+        (rc = c->b_out.reserve(static_cast<size_t>(out_off[n]) + 64)) || (rc = c->b_outoff.reserve(8 * static_cast<size_t>(n + 1))) ||
+        (rc = c->b_len.reserve(4 * static_cast<size_t>(n))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(c->b_in.p, in, static_cast<size_t>(in_off[n]), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->b_inoff.p, in_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->b_outoff.p, out_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+    sfa::InflateArgs ia{c->b_in.as<uint8_t>(), c->b_inoff.as<int64_t>(), c->b_out.as<uint8_t>(), c->b_outoff.as<int64_t>(), c->b_len.as<int32_t>(), n};
+    hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + sfa::kInfLanes - 1) / sfa::kInfLanes), dim3(64), 0, st, ia);
+    KERNEL_TRY();
+    HIP_TRY(hipMemcpyAsync(out, c->b_out.p, static_cast<size_t>(out_off[n]), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_len, c->b_len.p, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SFA_OK;
+}
+
 int sfa_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
     if (!free_bytes || !total_bytes) return fail(SFA_EINVAL, "sfa_device_memory: null argument");
     HIP_TRY(hipSetDevice(device));
@@ -1286,6 +1520,8 @@ int sfa_get_profile(sfa_ctx_t *c, sfa_profile_t *p) {
             sum.finalize_ms = std::max(sum.finalize_ms, q.finalize_ms);
             sum.total_ms = std::max(sum.total_ms, q.total_ms);
             sum.events_ms = std::max(sum.events_ms, q.events_ms);
+            sum.decode_ms = std::max(sum.decode_ms, q.decode_ms);
+            sum.blow5_fallbacks += q.blow5_fallbacks;
             sum.normalise_ms = std::max(sum.normalise_ms, q.normalise_ms);
             sum.cells += q.cells;
             sum.fill_launches += q.fill_launches;

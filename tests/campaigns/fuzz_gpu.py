@@ -59,6 +59,10 @@ def main():
         if rng.integers(0, 3) == 0:
             opts["lds_ckpt"] = 0  # every snapshot to HBM (default: rolling in LDS where the shapes allow)
         if rng.integers(0, 3) == 0:
+            opts["fused_trace"] = 0  # pass 2 as its own launch
+        if rng.integers(0, 4) == 0:
+            opts["lds_ckpt"] = 2  # LDS checkpoints whatever the batch size
+        if rng.integers(0, 3) == 0:
             opts["prio_unit"] = int(rng.choice([0, 64, 700]))
         opts["lane_widening"] = int(rng.choice([0, 1, 1, 2, 4]))  # small batches widen by themselves; pin the other shapes too
         if rng.integers(0, 2):  # column segments (small batches): forced counts and short warm-ups exercise the hand-over check

@@ -35,6 +35,7 @@ def assert_rows_equal(got, want):
 MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "lane_widening": 1},
          "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1}, "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2},
          "lds_wide4_backoff": {"trace_margin": 0, "lane_widening": 4, "column_segments": 1, "lds_ckpt": 2},
+         "lds_unfused": {"lds_ckpt": 2, "fused_trace": 0, "lane_widening": 1},
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
          "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
          "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}

@@ -3,5 +3,5 @@
 WL=${WL:-ncov_r9_dna_q250}
 for round in 1 2; do
 for n in "$@"; do
-  SFA_LIB=$GRAFT_REPO_ROOT/sigfish_amd/lib/libsfa_$n.so timeout -k 10 200 python bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$WL', '$n', d['value'], d['roofline']['kernel_ms_per_step'], d['roofline']['trace_kernel_ms_per_step'])"
+  SFA_LIB=$GRAFT_REPO_ROOT/sigfish_amd/lib/libsfa_$n.so timeout -k 10 200 python bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-e2e 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$WL', '$n', d['value'], d['roofline']['kernel_ms_per_step'], d['roofline']['trace_kernel_ms_per_step'])"
 done; done

@@ -57,7 +57,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
                     for i, line in enumerate(fi):
                         n += 1
                         if i < 5:  # first copy of the fixture's reads: same rows as the fixture, read ids carry the copy suffix
-                            a, b = line.split("\t"), want_head[i].split("\t")
+                            a, b = line.rstrip("\n").split("\t"), want_head[i].split("\t")
                             ok = ok and a[0] == b[0] + "_0" and a[1:] == b[1:]
                 if n != copies * 5 or not ok:
                     raise RuntimeError(f"end-to-end output differs from the fixture on the {kind} file at -K {k} ({n} rows)")

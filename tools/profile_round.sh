@@ -7,7 +7,7 @@ TAG=${1:?tag}; shift || true
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e $*"
 cd $ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o runc -- $BENCH > $OUT/kt.log 2>&1
 pass() {  # name counters...
