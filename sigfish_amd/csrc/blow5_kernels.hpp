@@ -19,7 +19,19 @@
 //     stream, a second scan of the zig-zag decoded deltas gives the samples, stored 8 bytes per lane, coalesced.
 #pragma once
 
+#ifdef SFA_HOST_HARNESS  // tests/c/device_inflate_host.cpp compiles the lane decoder below with g++ (sanitizers, against zlib)
+#include <string.h>
+#define __device__
+#define __forceinline__ inline
+static inline bool __any(bool x) { return x; }
+static inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i, x >>= 1) r = (r << 1) | (x & 1u);
+    return r;
+}
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace sfa {
@@ -52,29 +64,53 @@ __device__ const uint16_t kInfDistBase[30] = {1,   2,   3,   4,   5,   7,    9, 
 __device__ const uint8_t kInfDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ const uint8_t kInfClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// LSB-first bit reader over a byte range; reads 4 bytes at a time (the buffer is padded so that the over-read is harmless,
-// `avail` keeps the books on what was really there)
+// LSB-first bit reader over a byte range.  Input arrives 16 bytes at a time into a 128-bit shift register (lo, hi) with the NEXT
+// 16 bytes already requested (nlo, nhi): a load is issued sixteen-odd symbols before its first bit is looked at.  The buffer
+// is padded so that reading ahead is harmless; `avail` keeps the books on what was really part of the record.
+// (Measured and dropped, profiles/r02_logs/blow5_decode_variants.log: a 32-byte window per lane reloaded by all lanes of the
+// wave together, and 8-byte output stores -- both meant to spare the wave memory waits, both slower than this: what a wave
+// of independent decoders pays for is INSTRUCTIONS, every lane's rare path being executed by all of them; see
+// blow5_inflate_kernel for what does help.)
 struct BitReader {
-    const uint8_t *p;
-    int64_t avail;  // bits of the record not yet loaded into buf
+    const uint8_t *p;   // next 16 bytes to request
+    int64_t avail;      // bits of the record not yet moved into buf
     uint64_t buf;
-    int cnt;        // valid bits in buf (may include bits beyond the record once avail < 0: checked by need())
+    int cnt;            // valid bits in buf (may include bits beyond the record once avail < 0: see drop())
+    uint64_t lo, hi;    // words waiting to enter buf
+    uint64_t nlo, nhi;  // the 16 bytes behind them, in flight
+    int words;          // 32-bit words left in (lo, hi)
     bool overrun;
+    __device__ __forceinline__ static void load16(const uint8_t *q, uint64_t &a, uint64_t &b) {
+        uint64_t t[2];
+        __builtin_memcpy(t, q, 16);
+        a = t[0];
+        b = t[1];
+    }
     __device__ __forceinline__ void init(const uint8_t *b, int64_t nbytes) {
-        p = b;
         avail = nbytes * 8;
         buf = 0;
         cnt = 0;
         overrun = false;
+        load16(b, lo, hi);
+        load16(b + 16, nlo, nhi);
+        p = b + 32;
+        words = 4;
     }
+    __device__ __forceinline__ void sync() {}  // (hook of the dropped window variant; kept so that the loops read the same)
     __device__ __forceinline__ void refill() {
         if (cnt <= 32) {
-            uint32_t w;
-            __builtin_memcpy(&w, p, 4);
-            buf |= static_cast<uint64_t>(w) << cnt;
-            p += 4;
+            buf |= (lo & 0xffffffffull) << cnt;
+            lo = (lo >> 32) | (hi << 32);
+            hi >>= 32;
             cnt += 32;
             avail -= 32;
+            if (--words == 0) {
+                lo = nlo;
+                hi = nhi;
+                load16(p, nlo, nhi);
+                p += 16;
+                words = 4;
+            }
         }
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return static_cast<uint32_t>(buf) & ((1u << n) - 1u); }
@@ -114,19 +150,21 @@ __device__ __forceinline__ int inf_decode_slow(BitReader &br, const uint16_t *co
     return -1;
 }
 
-// counts + symbols in code order from code lengths; false on an over-subscribed or (where not allowed) incomplete code
-__device__ __forceinline__ bool inf_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, int maxlen, bool allow_incomplete) {
+// counts + symbols in code order from code lengths; false on an over-subscribed code and on the incomplete codes zlib's
+// inflate refuses (so that the device accepts exactly what the reference's reader accepts): an incomplete code is only
+// legal with a single code of length 1 (one distance used); `no_codes_ok`: an empty code (a block without matches);
+// `any`: the fixed distance code of RFC 1951 3.2.6, which has 30 of 32 codes by definition
+__device__ __forceinline__ bool inf_build(const uint8_t *lens, int n, uint16_t *count, uint16_t *sym, int maxlen, bool no_codes_ok, bool any = false) {
     for (int l = 0; l <= maxlen; ++l) count[l] = 0;
     for (int s = 0; s < n; ++s) count[lens[s]]++;
-    if (count[0] == n) return allow_incomplete;  // no codes at all
+    if (count[0] == n) return no_codes_ok;  // no codes at all
     int left = 1;
     for (int l = 1; l <= maxlen; ++l) {
         left <<= 1;
         left -= count[l];
         if (left < 0) return false;
     }
-    if (left > 0 && !allow_incomplete) {
-        // RFC 1951 allows exactly one incomplete case: a single code of length 1 (one distance code used)
+    if (left > 0 && !any) {
         int used = 0;
         for (int l = 1; l <= maxlen; ++l) used += count[l];
         if (!(used == 1 && count[1] == 1)) return false;
@@ -178,12 +216,17 @@ __device__ inline int inflate_zlib_lane(const uint8_t *in, int64_t n_in, uint8_t
     };
     uint8_t *lens = reinterpret_cast<uint8_t *>(S.fast);  // the first-level table's storage doubles as scratch for the code lengths
     for (;;) {
+        br.sync();
         const uint32_t last = br.get(1), type = br.get(2);
         if (type == 0) {  // stored
             br.align_byte();
             const uint32_t len = br.get(16), nlen = br.get(16);
             if ((len ^ 0xffffu) != nlen || op + len > cap) return -1;
-            for (uint32_t i = 0; i < len; ++i) emit(static_cast<uint8_t>(br.get(8)));
+            for (uint32_t i = 0; i < len; ++i) {
+                br.sync();
+                emit(static_cast<uint8_t>(br.get(8)));
+                if (br.overrun) return -1;  // (every loop checks: a corrupt length must not walk far beyond the record)
+            }
         } else if (type == 1 || type == 2) {
             int nlit, ndist;
             if (type == 1) {  // fixed code, RFC 1951 3.2.6
@@ -201,12 +244,17 @@ __device__ inline int inflate_zlib_lane(const uint8_t *in, int64_t n_in, uint8_t
                 if (nlit > 286 || ndist > 30) return -1;
                 uint8_t cl[19];
                 for (int i = 0; i < 19; ++i) cl[i] = 0;
-                for (int i = 0; i < ncl; ++i) cl[kInfClOrder[i]] = static_cast<uint8_t>(br.get(3));
+                br.sync();
+                for (int i = 0; i < ncl; ++i) {
+                    if ((i & 7) == 7) br.sync();
+                    cl[kInfClOrder[i]] = static_cast<uint8_t>(br.get(3));
+                }
                 if (!inf_build(cl, 19, S.ccount, S.csym, 7, false)) return -1;
                 int i = 0;
                 while (i < nlit + ndist) {
+                    br.sync();
                     const int sym = inf_decode_slow(br, S.ccount, S.csym, 7);
-                    if (sym < 0) return -1;
+                    if (sym < 0 || br.overrun) return -1;
                     if (sym < 16) {
                         lens[i++] = static_cast<uint8_t>(sym);
                     } else {
@@ -229,9 +277,10 @@ __device__ inline int inflate_zlib_lane(const uint8_t *in, int64_t n_in, uint8_t
                 for (int s = ndist - 1; s >= 0; --s) lens[288 + s] = lens[nlit + s];
             }
             if (!inf_build(lens, nlit, S.lcount, S.lsym, 15, false)) return -1;
-            if (!inf_build(lens + 288, ndist, S.dcount, S.dsym, 15, true)) return -1;
+            if (!inf_build(lens + 288, ndist, S.dcount, S.dsym, 15, true, type == 1)) return -1;
             inf_build_fast(S.lcount, S.lsym, S.fast);  // (overwrites `lens`: no longer needed)
             for (;;) {
+                br.sync();
                 br.refill();
                 int sym;
                 const uint32_t e = S.fast[br.peek(kInfFastBits)];
@@ -281,14 +330,18 @@ __device__ inline int inflate_zlib_lane(const uint8_t *in, int64_t n_in, uint8_t
 }
 
 #ifdef SFA_DEFINE_FINALIZE_KERNEL  // plain kernels: defined in exactly one translation unit
-// 32 records per 64-lane block: 32 x 1.8 KB of decoder state stay below the 64 KB a workgroup may always have, two blocks fit
-// a CU's 160 KB, and a batch of 8 192 records still puts one block on every CU
-constexpr int kInfLanes = 32;
-__global__ void __launch_bounds__(64) blow5_inflate_kernel(const InflateArgs a) {
-    __shared__ InflateLds lds_state[kInfLanes];
-    if (threadIdx.x >= kInfLanes) return;
-    InflateLds *S = &lds_state[threadIdx.x];
-    const int i = blockIdx.x * kInfLanes + threadIdx.x;
+// `lanes` records per wave (one wave per block, the other lanes idle), chosen by the host from the batch size
+// (inflate_lanes()).  A wave of independent decoders executes every lane's path: whenever ONE lane meets a code longer than
+// the first-level table, a match or a block header, all of them sit through it -- with 32 records per wave that is nearly
+// every iteration, and a batch took 6.5-10 ms whatever its size (one wave's serial time).  A batch of a few thousand records
+// is far too small to fill 1 024 SIMDs with full waves anyway, so the records are spread thin instead: enough waves for
+// about one per SIMD, down to ONE record per wave (no divergence at all), up to kInfMaxLanes for the largest batches.
+constexpr int kInfMaxLanes = 32;
+__global__ void __launch_bounds__(64) blow5_inflate_kernel(const InflateArgs a, const int lanes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (static_cast<int>(threadIdx.x) >= lanes) return;
+    InflateLds *S = reinterpret_cast<InflateLds *>(lds_raw) + threadIdx.x;
+    const int i = blockIdx.x * lanes + threadIdx.x;
     if (i >= a.n) return;
     const int64_t b = a.in_off[i], e = a.in_off[i + 1];
     const int64_t ob = a.out_off[i], oe = a.out_off[i + 1];

@@ -42,7 +42,7 @@ struct Opt {
     int verbosity = 4;
     std::vector<int> devices{0};  // --device 0,1,...: batches go to the devices in turn
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
-    bool host_parse = false;   // --host-parse: records are decompressed and parsed on host threads instead of the GPU
+    int gpu_parse = -1;        // --gpu-parse / --host-parse: records decompressed and parsed on the GPU / on host threads (-1: by device count)
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     const char *model_file = nullptr;
     const char *pore = nullptr;
@@ -96,7 +96,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --host-parse               decompress and parse the records on host threads instead of the GPU\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -224,7 +224,7 @@ static int dtw_run(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -276,7 +276,8 @@ static int dtw_run(int argc, char **argv) {
                 break;
             }
             case 14: o.host_events = true; break;
-            case 16: o.host_parse = true; break;
+            case 16: o.gpu_parse = 0; break;
+            case 17: o.gpu_parse = 1; break;
             case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }
@@ -403,9 +404,13 @@ static int dtw_run(int argc, char **argv) {
     // events on the GPU unless the RNA auto prefix is asked for (adaptor/poly-A detection stays on the host); for SAM the
     // event tables of the query windows come back from the device with the rows
     const bool gpu_events = !o.host_events && o.prefix >= 0;
-    // ... and so do the records themselves: inflate, field parsing and signal decoding run on the device (sfa_align_blow5); the
-    // host only frames the records and copies their bytes into page-locked staging
-    const bool gpu_parse = gpu_events && !o.host_parse;
+    // ... and so can the records themselves: inflate, field parsing and signal decoding on the device (sfa_align_blow5), the host
+    // only framing the records and copying their bytes into page-locked staging.  Measured on one GPU with 16 host threads
+    // (profiles/r02_logs/e2e_compressed_streams_x_batch.log): the two routes are level, 0.49-0.52 M reads/s from a compressed
+    // file -- 16 cores inflate 0.75 M records/s, the device 1.0 M/s but in competition with the alignment kernels for the same
+    // LDS -- and the host route is the better one at the default -K 4096.  What the device route buys is independence from the
+    // host: a node's cores do not grow with its GPUs, so it is the default from three devices on.
+    const bool gpu_parse = gpu_events && (o.gpu_parse < 0 ? o.devices.size() > 2 : o.gpu_parse == 1);
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);

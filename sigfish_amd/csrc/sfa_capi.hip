@@ -1308,6 +1308,14 @@ static int align_raw_impl(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_o
     return resolve_profile(c);
 }
 
+// records per wave of the device inflate: about one wave per SIMD (blow5_inflate_kernel)
+static int inflate_lanes(int32_t n, int cu_count) {
+    const int64_t simds = static_cast<int64_t>(cu_count) * 4;
+    int lanes = 1;
+    while (lanes < sfa::kInfMaxLanes && static_cast<int64_t>(n) > simds * lanes) lanes *= 2;
+    return lanes;
+}
+
 // BLOW5 records in, result rows out: records are decompressed and parsed on the device (blow5_kernels.hpp), then the path of
 // sfa_align_raw continues on the samples where they already are.
 int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off, int32_t n, int32_t record_zlib, int32_t signal_svb,
@@ -1343,7 +1351,7 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
     std::vector<int64_t> slot(n + 1);
     slot[0] = 0;
     for (int32_t i = 0; i < n; ++i) slot[i + 1] = slot[i] + (record_zlib ? (((rec_off[i + 1] - rec_off[i]) * 4 + 4096 + 15) & ~int64_t(15)) : 0);
-    if ((rc = c->b_in.reserve(static_cast<size_t>(in_bytes) + 64)) || (rc = c->b_inoff.reserve(8 * static_cast<size_t>(n + 1))) ||
+    if ((rc = c->b_in.reserve(static_cast<size_t>(in_bytes) + 128)) || (rc = c->b_inoff.reserve(8 * static_cast<size_t>(n + 1))) ||
         (rc = c->b_head.reserve(static_cast<size_t>(n) * sfa::kBlow5HeadBytes)) || (rc = c->h_head.reserve(static_cast<size_t>(n) * sfa::kBlow5HeadBytes + 8 * static_cast<size_t>(n))) ||
         (rc = c->b_len.reserve(4 * static_cast<size_t>(n))) || (rc = c->b_bad.reserve(4 * static_cast<size_t>(n))))
         return rc;
@@ -1356,7 +1364,8 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
     if (record_zlib) {
         HIP_TRY(hipMemcpyAsync(c->b_outoff.p, slot.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
         sfa::InflateArgs ia{c->b_in.as<uint8_t>(), c->b_inoff.as<int64_t>(), c->b_out.as<uint8_t>(), c->b_outoff.as<int64_t>(), c->b_len.as<int32_t>(), n};
-        hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + sfa::kInfLanes - 1) / sfa::kInfLanes), dim3(64), 0, st, ia);
+        const int lanes = inflate_lanes(n, c->cu_count);
+        hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + lanes - 1) / lanes), dim3(64), sizeof(sfa::InflateLds) * lanes, st, ia, lanes);
         KERNEL_TRY();
         fa.payload = c->b_out.as<uint8_t>();
         fa.payload_off = c->b_outoff.as<int64_t>();
@@ -1387,6 +1396,8 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
         memcpy(&id_len, h + 4, 4);
         memcpy(&ns, h + 8, 8);
         if (status != 0 || id_len < 0 || id_len > static_cast<int32_t>(sizeof(heads[i].read_id)) - 1 || ns < 0) {
+            (void)fail(SFA_OK, "sfa_align_blow5: device declined record %d (status %d, id of %d bytes, %lld samples): host reader takes the batch", i,
+                       status, id_len, static_cast<long long>(ns));  // kept in sfa_last_error() for whoever wants to know why
             fallback = true;
             break;
         }
@@ -1415,7 +1426,11 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
         HIP_TRY(hipMemcpyAsync(bad, c->b_bad.p, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(c->bev[1], st));
         HIP_TRY(hipStreamSynchronize(st));
-        for (int32_t i = 0; i < n && !fallback; ++i) fallback = bad[i] != 0;
+        for (int32_t i = 0; i < n && !fallback; ++i)
+            if (bad[i] != 0) {
+                (void)fail(SFA_OK, "sfa_align_blow5: signal of record %d is shorter than its keys say: host reader takes the batch", i);
+                fallback = true;
+            }
         if (!fallback) {
             c->bev_pending = true;
             return align_raw_impl(c, nullptr, raw_off.data(), scaling.data(), n, prefix_size, query_size, rows, info, query_events);
@@ -1457,7 +1472,7 @@ int sfa_inflate_zlib_device(sfa_ctx_t *c, const uint8_t *in, const int64_t *in_o
     HIP_TRY(hipStreamSynchronize(c->stream));
     hipStream_t st = c->stream;
     int rc;
-    if ((rc = c->b_in.reserve(static_cast<size_t>(in_off[n]) + 64)) || (rc = c->b_inoff.reserve(8 * static_cast<size_t>(n + 1))) ||
+    if ((rc = c->b_in.reserve(static_cast<size_t>(in_off[n]) + 128)) || (rc = c->b_inoff.reserve(8 * static_cast<size_t>(n + 1))) ||
         (rc = c->b_out.reserve(static_cast<size_t>(out_off[n]) + 64)) || (rc = c->b_outoff.reserve(8 * static_cast<size_t>(n + 1))) ||
         (rc = c->b_len.reserve(4 * static_cast<size_t>(n))))
         return rc;
@@ -1465,7 +1480,8 @@ int sfa_inflate_zlib_device(sfa_ctx_t *c, const uint8_t *in, const int64_t *in_o
     HIP_TRY(hipMemcpyAsync(c->b_inoff.p, in_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->b_outoff.p, out_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
     sfa::InflateArgs ia{c->b_in.as<uint8_t>(), c->b_inoff.as<int64_t>(), c->b_out.as<uint8_t>(), c->b_outoff.as<int64_t>(), c->b_len.as<int32_t>(), n};
-    hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + sfa::kInfLanes - 1) / sfa::kInfLanes), dim3(64), 0, st, ia);
+    const int lanes = inflate_lanes(n, c->cu_count);
+    hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + lanes - 1) / lanes), dim3(64), sizeof(sfa::InflateLds) * lanes, st, ia, lanes);
     KERNEL_TRY();
     HIP_TRY(hipMemcpyAsync(out, c->b_out.p, static_cast<size_t>(out_off[n]), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_len, c->b_len.p, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, st));

@@ -124,7 +124,7 @@ def test_align_blow5_equals_align_raw(name, press, tmp_path):
             assert [(h["digitisation"], h["offset"], h["range"]) for h in heads] == [tuple(m) for m in meta]
             assert [h["record_bytes"] for h in heads] == [len(r) for r in recs]
             p = a.profile()
-            assert p["blow5_fallbacks"] == 0 and (a is two or p["decode_ms"] > 0)
+            assert p["blow5_fallbacks"] == 0 and (a is two or p["decode_ms"] > 0), a._L.sfa_last_error()
 
 
 def test_align_blow5_falls_back_to_the_host_reader(tmp_path):

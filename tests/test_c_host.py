@@ -82,3 +82,21 @@ def test_host_units_under_sanitizers(tmp_path):
                           os.path.join(data, "random", "rnd_dna.blow5")], capture_output=True, timeout=600)
     assert run.returncode == 0, (run.stdout + run.stderr).decode()[-3000:]
     assert b"ERROR: AddressSanitizer" not in run.stderr and b"runtime error" not in run.stderr, run.stderr.decode()[-3000:]
+
+
+def test_device_inflate_lane_decoder_on_the_host_with_sanitizers(tmp_path):
+    """The per-lane DEFLATE decoder of the device-side BLOW5 reader (blow5_kernels.hpp: the body of blow5_inflate_kernel),
+    compiled for the host: against zlib on 4 000 random streams (every block type, encoder setting and window size,
+    arbitrary bytes behind the stream), too-small output slots, corrupted streams -- under ASan + UBSan, which the GPU pool
+    cannot run."""
+    import shutil
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "device_inflate_host")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                            os.path.join(ROOT, "tests", "c", "device_inflate_host.cpp"), "-lz"], capture_output=True, timeout=600)
+    if build.returncode != 0 and b"sanitize" in build.stderr:
+        pytest.skip("toolchain without sanitizer runtimes")
+    assert build.returncode == 0, build.stderr.decode()[-2000:]
+    run = subprocess.run([exe, "4000", "3"], capture_output=True, timeout=900)
+    assert run.returncode == 0 and b"4000 iterations, 0 failures" in run.stdout, (run.stdout + run.stderr).decode()[-3000:]

@@ -41,11 +41,11 @@ def test_cli_matches_reference_output(name, models):
     assert r.stdout.decode() == c["out_text"]
 
 
-@pytest.mark.parametrize("stage", ["--host-events", "--host-parse"])
+@pytest.mark.parametrize("stage", ["--host-events", "--gpu-parse"])
 @pytest.mark.parametrize("name", ["dna_default", "dna_from_end", "rna_default", "rna_full_ref_dtw_std", "dna_sam", "rna_sam", "rna_q2000_sam", "rna_q2500", "rna_q4200_full_sam"])
 def test_cli_host_events_path(name, stage, models):
-    """--host-events forces event detection onto host threads, --host-parse only the record decompression / parsing (the
-    default does both on the GPU); output must be identical."""
+    """--host-events forces event detection onto host threads, --gpu-parse moves the record decompression / parsing onto the
+    GPU as well (the default up to two devices: events on the GPU, records on host threads); output must be identical."""
     c = load_case(name)
     args = [str(a) for a in c["args"]]
     cmd = [BIN, "dtw", "--kmer-model", models[c["k"]], "--verbose", "0", stage, *args, c["fasta"], c["blow5"]]
@@ -96,7 +96,7 @@ RANDOM_CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(G
 
 
 @pytest.mark.parametrize("name", RANDOM_CASES)
-@pytest.mark.parametrize("extra", [[], ["-K", "7"], ["--host-events"], ["--host-parse"], ["--host-parse", "-K", "7"]])
+@pytest.mark.parametrize("extra", [[], ["-K", "7"], ["--host-events"], ["--gpu-parse"], ["--gpu-parse", "-K", "7"]])
 def test_cli_random_signal_goldens(name, extra, models):
     """Synthetic step signals in compressed BLOW5 files (40 reads each) whose PAF / SAM text the compiled reference
     printed (tests/golden/random, oracle/make_golden.py): the command line must print the same, through device-side and

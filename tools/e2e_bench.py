@@ -63,6 +63,17 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
                     raise RuntimeError(f"end-to-end output differs from the fixture on the {kind} file at -K {k} ({n} rows)")
                 out["reads"] = n
                 out[f"{kind}_K{k}"] = round(n / dt, 1)
+            if kind == "compressed":  # the same file with the records decompressed and parsed on the device (sfa_align_blow5)
+                t0 = time.perf_counter()
+                with open(os.path.join(d, "out.paf"), "wb") as fo:
+                    r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", "8192", "-B", "2G", "--verbose", "0",
+                                        "--gpu-parse", "--streams", "4", os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path],
+                                       stdout=fo, stderr=subprocess.PIPE)
+                dt = time.perf_counter() - t0
+                rows = sum(1 for _ in open(os.path.join(d, "out.paf")))
+                if r.returncode != 0 or rows != copies * 5:
+                    raise RuntimeError(f"sigfish-amd dtw --gpu-parse failed on the compressed file: {r.stderr.decode()[-300:]}")
+                out["compressed_gpu_parse_K8192_streams4"] = round(rows / dt, 1)
             os.remove(path)
         out["parity"] = "row count and the first five rows (= the reference's PAF for the fixture) checked in every run"
     finally:
