@@ -126,6 +126,7 @@ struct DpArgs {
     int32_t coarse_every;  // every coarse_every-th LDS snapshot also goes to the HBM checkpoint store (ck_shift = 9 + log2 of it)
     // fused launch (FUSED kernels): waves claim tickets; tickets < n_tasks are fill tasks, ticket n_tasks + q is pass 2 of quad q,
     // which waits until quad_done[q] == n_chunks.  Rows are written by the pass-2 waves (tables as FinalizeArgs).
+    const struct DpArgs *self;  // this very block in device memory: what the pass-2 function of the fused launch reads (see there)
     unsigned *ticket;
     int32_t *quad_done;
     int32_t n_quads_total;
@@ -410,7 +411,7 @@ struct LdsCkpt {
     }
     // at the end of a window that began at step e_ws (steps since t_begin) and became the best of some read(s) of the quad:
     // improved = ballot of the lanes owning the last query row of those reads.  All 64 lanes are active here.
-    template <int R, int L>
+    template <int R, int L, bool WT = false>  // WT: write-through stores (the fused launch reads the record in the same launch)
     __device__ __forceinline__ void save(unsigned long long improved, float wmin, int e_ws, int margin, int lq, int job) {
         const int lane = threadIdx.x & 63;
         const int owner_lane = (lane & ~(L - 1)) + lq;
@@ -427,16 +428,27 @@ struct LdsCkpt {
         if (kk > 0) {
             const float *b = buf + (kk & 1) * (kLdsCkPlanes * 64);
 #pragma unroll
-            for (int r = 0; r <= R; ++r) rec[r * 64] = b[r * 64];
+            for (int r = 0; r <= R; ++r) {
+                if (WT)
+                    __hip_atomic_store(rec + r * 64, b[r * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    rec[r * 64] = b[r * 64];
+            }
         }
-        if (lane == owner_lane) rec_e[lane / L] = kk > 0 ? ((kk & 1) ? e1 : e0) : -1;
+        if (lane == owner_lane) {
+            const int ev = kk > 0 ? ((kk & 1) ? e1 : e0) : -1;
+            if (WT)
+                __hip_atomic_store(rec_e + lane / L, ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                rec_e[lane / L] = ev;
+        }
         (void)job;
     }
 };
 
 // One (contig,strand) sweep of a quad.  RQ >= 0: the register holding the last query row is a compile-time
 // constant (hot specialisation); RQ < 0: it is the wave-uniform value rq (indexed v_mov).
-template <int R, bool TRACK, bool STD, int RQ, bool LCK = false, int L = 16>
+template <int R, bool TRACK, bool STD, int RQ, bool LCK = false, int L = 16, bool WT = false>
 __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
                                           const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<TRACK> &top,
                                           const int job, float *ckp, const int T, IssuePriority &pr, LdsCkpt *lck = nullptr,
@@ -561,7 +573,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             const bool became_best = top.offer(wmin, TRACK ? wpos : col, wst, job);  // cost-only: the window is identified by its first column
             if (LCK) {
                 const unsigned long long improved = __ballot(became_best && owner);
-                if (improved) lck->template save<R, L>(improved, wmin, col + e_main, a.trace_margin, lq, job);
+                if (improved) lck->template save<R, L, WT>(improved, wmin, col + e_main, a.trace_margin, lq, job);
             }
         } else {  // std_dtw: the single candidate C[n-1][m-1]
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
@@ -575,17 +587,17 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
 
 // Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill (worth
 // 5-20 % on the small-batch shapes, whose steps are short).
-template <int R, bool TRACK, bool STD, bool LCK = false, int L = 16, int I = 0>
+template <int R, bool TRACK, bool STD, bool LCK = false, int L = 16, bool WT = false, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
                                                const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T,
                                                IssuePriority &pr, LdsCkpt *lck = nullptr, bool owner = false) {
     if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
-        sweep_job<R, TRACK, STD, -1, LCK, L>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
+        sweep_job<R, TRACK, STD, -1, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
     } else {
         if (rq == I) {
-            sweep_job<R, TRACK, STD, I, LCK, L>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
+            sweep_job<R, TRACK, STD, I, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, LCK, L, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
+            sweep_dispatch<R, TRACK, STD, LCK, L, WT, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
         }
     }
 }
@@ -640,26 +652,43 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         lck.rec_e = a.best_e + task * 4;
         lck.g_best = a.g_best + (read >= 0 ? read : 0);
         lck.e0 = lck.e1 = 0;
-        if (g == lq && read >= 0) lck.rec_e[slot] = -1;  // nothing saved yet: pass 2 starts the strand from scratch
+        if (g == lq && read >= 0) {  // nothing saved yet: pass 2 starts the strand from scratch
+            if (FUSED)
+                __hip_atomic_store(lck.rec_e + slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                lck.rec_e[slot] = -1;
+        }
     }
     for (int job = jb; job < je; ++job) {
         const int rlen = a.job_len[job];
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD, LCK, L>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, &lck, g == lq && read >= 0);
+        sweep_dispatch<R, TRACK, STD, LCK, L, FUSED>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, &lck, g == lq && read >= 0);
     }
 
     if (g == lq && read >= 0) {
         const int64_t o = (static_cast<int64_t>(quad) * a.n_chunks + chunk) * 4 + slot;
-        a.p_best[o] = top.best;
-        a.p_second[o] = top.second;
-        a.p_end[o] = top.end;
-        a.p_job[o] = top.job;
-        if (TRACK) a.p_st[o] = top.st;
+        if (FUSED) {  // (write-through, see below)
+            __hip_atomic_store(a.p_best + o, top.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.p_second + o, top.second, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.p_end + o, top.end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.p_job + o, top.job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            a.p_best[o] = top.best;
+            a.p_second[o] = top.second;
+            a.p_end[o] = top.end;
+            a.p_job[o] = top.job;
+            if (TRACK) a.p_st[o] = top.st;
+        }
     }
-    if (FUSED) {  // partial results and best-window records of this task are complete: publish, then count the quad's task in
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (FUSED) {
+        // Partial results and best-window records of this task are complete: publish, then count the quad's task in.  Everything
+        // a pass-2 wave will read was stored WRITE-THROUGH (agent-scope atomic stores: global_store ... sc1), so all that is
+        // left to do is to wait for those stores (a workgroup-scope release is exactly s_waitcnt vmcnt(0)).  The textbook
+        // agent-scope release fence would write back the whole L2 of the XCD at the end of every one of 50 000 tasks:
+        // measured as 2.07 GB of WRITE_SIZE per launch instead of 0.3 (profiles/r02_v2 vs r02_v3).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_fetch_add(a.quad_done + quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         set_issue_priority(0);
     }
@@ -859,11 +888,13 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 // is not touched by it.
 // pass 2 of one quad inside the fill launch (FUSED kernels; defined behind the trace code)
 // (not inlined: its register needs -- 128 VGPRs and some spills -- then stay its own business instead of leaning on the
-// allocation of the fill loops it shares the kernel with; and the arguments BY VALUE: a reference would force the kernel to
-// keep a copy of its kernarg block in scratch, and the fill loops would then read `a.xyz` from there, per lane, instead of
-// from scalar registers -- measured as a scratch load in every block of four steps)
+// allocation of the fill loops it shares the kernel with; and its arguments come from a copy of the kernarg block in DEVICE
+// memory (`a.self`): a reference to the kernel's own parameter would force the kernel to keep a copy of it in scratch, and
+// the fill loops would then read `a.xyz` from there, per lane, instead of from scalar registers -- measured as a scratch
+// load in every block of four steps; passing the 600-byte block by value costs a per-LANE stack copy per call instead,
+// 0.95 GB of scratch writes per 100 000-read launch)
 template <int MAXR>
-__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs a, const int quad, float *lds_f, int *lds_i);
+__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i);
 
 // LCK: rolling checkpoints in LDS (LdsCkpt) -- two snapshots of 17 planes per wave, 34 KB per block, four blocks per CU.
 // FUSED (with LCK): pass 2 rides in the same launch.  Waves claim TICKETS from a counter instead of deriving their task from
@@ -907,7 +938,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
         task = __builtin_amdgcn_readfirstlane(t);
         if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
             const int quad = task - a.n_tasks;
-            if (quad < a.n_quads_total) fused_trace_dispatch<MAXR>(a, quad, lds_f, lds_i);  // ONE call site: one argument copy on the stack
+            if (quad < a.n_quads_total) fused_trace_dispatch<MAXR>(a.self, quad, lds_f, lds_i);
             return;
         }
     }
@@ -1267,7 +1298,8 @@ __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDes
 }
 
 template <int MAXR>
-__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs a, const int quad, float *lds_f, int *lds_i) {
+__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i) {
+    const DpArgs &a = *pa;
     int ci = 0;
     while (ci + 1 < a.n_cls && quad >= a.cls[ci + 1].quad_base) ++ci;
     const ClassDesc cd = a.cls[ci];

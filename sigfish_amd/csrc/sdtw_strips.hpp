@@ -46,9 +46,9 @@ struct StripArgs {
     float *bnd_cost;          // [n_long][2 buffers][bnd_off[n_jobs]] last-row costs of the previous / current strip
     int32_t *bnd_start;       // [n_long][2 buffers][bnd_row_max] carried start columns (pass 2: one job per read)
     int64_t bnd_row_max;      // words of the longest boundary row
-    float *p_best, *p_second; // pass 1: partial top-2 per (long read, job); p_end = first column of the best window
+    float *p_best, *p_second; // pass 1: partial top-2 per (long read, job); p_end = column of the best window's first strict minimum
     int32_t *p_end;
-    const int32_t *w_job;     // pass 2: winner per long read (from the strip finalize): job, first column of the window, score
+    const int32_t *w_job;     // pass 2: winner per long read (from the strip finalize): job, column of the winning cell, score
     const int32_t *w_ws;
     const float *w_score;
     int32_t *t_st, *t_end;    // pass 2 out: start / end column of the winning alignment per long read
@@ -58,7 +58,14 @@ struct StripArgs {
     int32_t max_strips;       // strips of the longest query of the launch
     int32_t trace_margin;     // pass 2 resumes at least this many columns before the winning window; < 0: query length + 64
     int32_t n_long, n_jobs, rev_query;
+    // pipelined pass 1 (sdtw_strip_pipe_kernel): one wave per (read, job, STRIP); strip s + 1 follows strip s through HBM
+    int64_t bnd_stride;         // floats between two reads' boundary buffers (pipelined pass 1: max_strips - 1 rows, else 2)
+    const int32_t *strip_off;   // [n_long+1] prefix sum of the reads' strip counts
+    int32_t *progress;          // [n_long][n_jobs][max_strips] columns of the strip's last row that are complete and visible
+    unsigned *ticket;           // task counter (zeroed before the launch)
 };
+
+constexpr int kPipeBlock = 1024;  // columns between two hand-overs of a boundary row (one release / acquire pair each)
 
 // One anti-diagonal step of a strip: dp_step<32, TRACK> with the handling of query row 0 made conditional on FIRST (the
 // strip that contains it).
@@ -123,7 +130,9 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                                             const float (&x)[kStripR], const int lq, const int rq, const int lane, Exchange &xc,
                                             const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
                                             const int job, const int ws, const float best, const int t_begin, float *ckp,
-                                            const int ck_shift, const int nck) {
+                                            const int ck_shift, const int nck, const int32_t *prog_in = nullptr, int32_t *prog_out = nullptr) {
+    // prog_in / prog_out (pipelined pass 1): how far the strip above has got with the row this sweep reads / where to say how
+    // far this sweep has got with the row it writes.  Both wave-uniform; nullptr: the rows are complete / nobody is waiting.
     // ckp: this strip's checkpoint records (+ lane).  Pass 1 stores record k - 1 before step k*T; pass 2 resumes from the
     // record of step t_begin (t_begin = 0: from the initial state).
     typename Vec<float, kStripR>::type c;
@@ -152,13 +161,28 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     const int T = 1 << ck_shift;
     const int ck_last = nck << ck_shift;
 
-    // pass 1, final strip: window scan of the last row (src/sigfish.c:891-901) -- only the minimum of every window is kept,
-    // the window is named by its first column; std_dtw has the single candidate C[n-1][m-1]
+    // pass 1, final strip: window scan of the last row (src/sigfish.c:891-901): the first strict minimum of every window AND
+    // its column (two more operations per step, against the 100 a strip's step has anyway -- the wave kernels cannot afford
+    // them); std_dtw has the single candidate C[n-1][m-1].  Knowing the winning CELL, pass 2 stops there and starts a query
+    // length in front of it instead of in front of its window: half the steps.
     float wmin = INFINITY;
-    int wcol0 = 0;
+    int wpos = -1;
     int wend = min(qlen, rlen);
 
     const int n_steps = ncols + lq;  // lane lq meets column ncols - 1 at step ncols - 1 + lq
+    // hand-over of the boundary row in blocks of kPipeBlock columns.  The consumer reads one block of four columns ahead, the
+    // producer's lane 63 writes column t - 63 at step t: before a consumer enters steps [t0, t0 + kPipeBlock) it wants columns
+    // below t0 + kPipeBlock + 8; at the top of its block t0 a producer has completed the columns below t0 - 64.
+    int wait_next = t_begin, pub_next = t_begin + kPipeBlock;
+    auto wait_for_row = [&](int t0) {
+        const int need = min(ncols, t0 + kPipeBlock + 8);
+        if (lane == 0)
+            while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        wait_next = t0 + kPipeBlock;
+    };
+    if (!FIRST && prog_in) wait_for_row(t_begin);
     float4u ycur = *reinterpret_cast<const float4u *>(yp + t_begin);
     float4a bc{};
     int4a bs{};
@@ -168,6 +192,12 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     }
     for (int t0 = t_begin; t0 < n_steps; t0 += 4) {
         if (!TRACK) {
+            if (!FIRST && prog_in && t0 >= wait_next) wait_for_row(t0);
+            if (prog_out && t0 >= pub_next) {  // the stores of the columns below t0 - 64 become visible, then the counter says so
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(prog_out, t0 - 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pub_next = t0 + kPipeBlock;
+            }
             if (t0 > 0 && (t0 & (T - 1)) == 0 && t0 <= ck_last) {  // wave-uniform: snapshot of the state before step t0
                 float *rec = ckp + static_cast<int64_t>((t0 >> ck_shift) - 1) * ((kStripR + 1) * 64);
 #pragma unroll
@@ -212,11 +242,13 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                         res.cap_end = hit ? col : res.cap_end;
                         res.cap_st = hit ? static_cast<int>(s[rq]) : res.cap_st;
                     } else if (!STD) {
-                        wmin = fminf(wmin, cl);
+                        const bool lt = cl < wmin;
+                        wmin = lt ? cl : wmin;
+                        wpos = lt ? col : wpos;
                         if (col + 1 == wend) {
-                            res.top.offer(wmin, wcol0, -1, job);
+                            res.top.offer(wmin, wpos, -1, job);
                             wmin = INFINITY;
-                            wcol0 = wend;
+                            wpos = -1;
                             wend = min(wend + qlen, rlen);
                         }
                     } else if (col == rlen - 1) {
@@ -228,6 +260,10 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
         ycur = ynext;
         bc = bcn;
         bs = bsn;
+    }
+    if (!TRACK && prog_out) {  // the whole row is there
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(prog_out, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -260,7 +296,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
     const int rlen = a.job_len[job];
     const float *yp = a.ref + a.job_off[job] - lane;  // this lane's column at step t is t - lane
     const int64_t per = a.bnd_off[a.n_jobs];
-    float *bc = a.bnd_cost + static_cast<int64_t>(li) * 2 * per + a.bnd_off[job];
+    float *bc = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];
     int32_t *bs = TRACK ? a.bnd_start + static_cast<int64_t>(li) * 2 * a.bnd_row_max : nullptr;
 
     int ws = 0, ncols = rlen;
@@ -271,7 +307,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
     if (TRACK) {
         ws = a.w_ws[li];
         best = a.w_score[li];
-        ncols = STD ? rlen : min(rlen, ws + qlen);  // columns up to the end of the winning window
+        ncols = STD ? rlen : min(rlen, ws + 1);  // columns up to the winning cell (pass 1 names it: p_end is its column)
         // every cell of a path that starts at or behind column k*T is evaluated after step k*T in every strip; a path of
         // qlen events rarely spans more than qlen columns -- and when it does, the read backs off
         const int from = ws - (a.trace_margin >= 0 ? a.trace_margin : qlen + 64);
@@ -332,7 +368,86 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
     }
 }
 
+// Pass 1, pipelined: wave-task = (job, long read, STRIP).  The classic pass 1 above gives one wave all the strips of a (read,
+// job), one after the other: few, long tasks -- 6 250 of them for 3 125 reads of 8 000 events, two-and-a-bit rounds of the
+// resident waves, each four sweeps long (0.69 x 10^13 cells/s against 1.9 x 10^13 for the wave kernels).  Here every strip is
+// its own wave, and strip s + 1 FOLLOWS strip s over the same columns, a block of kPipeBlock columns behind, reading the
+// boundary row strip s writes (one row per strip instead of two rows in turn).  Waves claim tickets in the order job, read,
+// strip: a strip's predecessor always holds a lower ticket, i.e. is running or done whenever the strip waits for it -- no
+// deadlock whatever order the hardware starts blocks in.  Everything else (checkpoints per strip, window scan in the final
+// strip, partial top-2 per (read, job)) is the classic pass 1's.
+template <bool STD>
+__global__ void __launch_bounds__(256, 2) sdtw_strip_pipe_kernel(const StripArgs a) {
+    const int lane = threadIdx.x & 63;
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int task = __builtin_amdgcn_readfirstlane(t);
+    const int total = a.strip_off[a.n_long];  // strips of all long reads of the group
+    if (task >= total * a.n_jobs) return;
+    const int job = task / total;
+    const int r = task - job * total;
+    int lo = 0, hi = a.n_long;  // the read whose strips hold index r: strip_off[li] <= r < strip_off[li + 1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.strip_off[mid] <= r)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const int li = lo, sidx = r - a.strip_off[li];
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[1];
+    Exchange xc;
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
+
+    const int read = a.reads[li];
+    const int64_t qo = a.q_off[read];
+    const int qlen = static_cast<int>(a.q_off[read + 1] - qo);
+    const float *q = a.queries + qo;
+    const int n_strips = (qlen + kStripRows - 1) / kStripRows;
+    const int rlen = a.job_len[job];
+    const float *yp = a.ref + a.job_off[job] - lane;
+    const int64_t per = a.bnd_off[a.n_jobs];
+    float *rows = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];  // row s at rows + s * per
+    int32_t *prog = a.progress + (static_cast<int64_t>(li) * a.n_jobs + job) * a.max_strips;
+    const int nck = (rlen - 1) >> a.ck_shift;
+    float *ckp = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * ((kStripR + 1) * 64) + lane +
+                 static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
+    const int row0 = sidx * kStripRows;
+    const int nrows = min(kStripRows, qlen - row0);
+    const bool last = sidx == n_strips - 1;
+    const int lq = (nrows - 1) / kStripR;
+    const int rq = (nrows - 1) - lq * kStripR;
+    float x[kStripR];
+#pragma unroll
+    for (int rr = 0; rr < kStripR; ++rr) {
+        const int i = row0 + lane * kStripR + rr;
+        const int src = a.rev_query ? (qlen - 1 - i) : i;
+        x[rr] = (i < qlen) ? q[src] : 0.0f;
+    }
+    StripResult res;
+    res.top.init();
+    res.cap_end = -1;
+    res.cap_st = -1;
+    float *bout_c = last ? nullptr : rows + static_cast<int64_t>(sidx) * per;
+    const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
+    if (sidx == 0)
+        strip_sweep<STD, true, false>(yp, rlen, rlen, qlen, last, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0, ckp,
+                                      a.ck_shift, nck, nullptr, last ? nullptr : prog + sidx);
+    else
+        strip_sweep<STD, false, false>(yp, rlen, rlen, qlen, last, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0, ckp,
+                                       a.ck_shift, nck, prog + sidx - 1, last ? nullptr : prog + sidx);
+    if (last && lane == lq) {
+        const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
+        a.p_best[o] = res.top.best;
+        a.p_second[o] = res.top.second;
+        a.p_end[o] = res.top.end;
+    }
+}
+
 // instantiated in sdtw_inst_strips.hip
+extern template __global__ void sdtw_strip_pipe_kernel<false>(const StripArgs);
+extern template __global__ void sdtw_strip_pipe_kernel<true>(const StripArgs);
 extern template __global__ void sdtw_strip_kernel<false, false>(const StripArgs);
 extern template __global__ void sdtw_strip_kernel<true, false>(const StripArgs);
 extern template __global__ void sdtw_strip_kernel<false, true>(const StripArgs);

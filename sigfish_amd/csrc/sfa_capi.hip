@@ -141,6 +141,7 @@ struct sfa_ctx {
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
+    int64_t opt_strip_pipeline = 1;          // row strips, pass 1: one wave per strip following the strip above (1) or one wave per (read, job) (0)
     int64_t opt_fused_trace = 1;             // 1: with LDS checkpoints, pass 2 rides in the fill launch as trailing tickets (fills the drain)
     int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
     int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
@@ -153,6 +154,7 @@ struct sfa_ctx {
 
     // per-batch scratch
     DevBuf d_verify, d_segfail;
+    DevBuf d_lprog, d_lticket;  // pipelined strips: progress counters, ticket
     DevBuf d_bndc, d_bnds, d_long, d_lbest, d_lsecond, d_lend, d_lwin, d_lck;  // row strips (queries beyond SFA_MAX_QUERY, sdtw_strips.hpp)
     PinBuf h_long;
     bool long_pending = false;
@@ -169,6 +171,7 @@ struct sfa_ctx {
     hipEvent_t bev[2] = {nullptr, nullptr};  // record decoding start / end
     bool bev_pending = false;
     int64_t blow5_fallbacks = 0;  // batches handed to the host reader because the device declined a record
+    DevBuf d_args;  // fused launch: the kernel's argument block in device memory (DpArgs::self)
     DevBuf d_ticket, d_quaddone;  // fused launch: ticket counter, completed fill tasks per quad
     DevBuf d_bestrec, d_beste, d_gbest, d_wchunk;  // LDS-checkpoint fill: records of the best windows, their step, per-read best score, winning chunk
     DevBuf d_bad, d_badcount;  // sdtw_screen_kernel: per-read flag, number of flagged reads
@@ -282,11 +285,15 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
 // tracking up to the end of the winning window.  Runs after the wave kernels of the batch, on the same stream, and
 // overwrites the (invalid) rows they left for these reads.  Reads are taken in groups whose boundary rows fit the
 // checkpoint budget.
-int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const std::vector<int32_t> &reads, int64_t max_qlen, ResultRow *d_out) {
+int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const int64_t *q_off_host, const std::vector<int32_t> &reads, int64_t max_qlen,
+               ResultRow *d_out) {
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
     const size_t o_reads = 0, o_bnd = (sizeof(int32_t) * n_long + 7) & ~size_t(7);
     const size_t o_ck = o_bnd + sizeof(int64_t) * (n_jobs + 1);
-    const size_t stage_bytes = o_ck + sizeof(int64_t) * (n_jobs + 1);
+    const size_t o_soff = o_ck + sizeof(int64_t) * (n_jobs + 1);  // per-group prefix sums of the reads' strip counts (filled per group)
+    const size_t stage_bytes = o_soff + sizeof(int32_t) * (static_cast<size_t>(n_long) + 2);
+    std::vector<int32_t> n_strips_of(n_long);
+    for (int32_t i = 0; i < n_long; ++i) n_strips_of[i] = static_cast<int32_t>((q_off_host[reads[i] + 1] - q_off_host[reads[i]] + sfa::kStripRows - 1) / sfa::kStripRows);
     int rc;
     if ((rc = c->h_long.reserve(stage_bytes)) || (rc = c->d_long.reserve(stage_bytes))) return rc;
     char *hs = c->h_long.as<char>();
@@ -318,12 +325,16 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         if (c->opt_ckpt_interval > 0 || recs * rec_floats * 4 * n_long <= c->opt_ckpt_budget || ck_shift >= 14) break;
     }
     const int64_t ck_floats_per_read = ck_off[n_jobs] * rec_floats;
-    // two buffers: costs of every job's row (pass 1), start columns of one row (pass 2); + the checkpoints
-    const int64_t bytes_per_read = (per + row_max) * 2 * 4 + ck_floats_per_read * 4;
+    // cost rows of every job: two in turn (classic pass 1, pass 2) or one per strip boundary (pipelined pass 1); start columns of
+    // one job, two in turn (pass 2); + the checkpoints
+    const bool pipe = c->opt_strip_pipeline != 0;
+    const int64_t cost_rows = pipe ? std::max<int64_t>(2, max_strips - 1) : 2;
+    const int64_t bytes_per_read = (per * cost_rows + row_max * 2) * 4 + ck_floats_per_read * 4;
     const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(n_long, c->opt_ckpt_budget / std::max<int64_t>(bytes_per_read, 1))));
     const size_t n_part = static_cast<size_t>(n_long) * n_jobs;
     const size_t bndc_cap = c->d_bndc.cap;
-    if ((rc = c->d_bndc.reserve(sizeof(float) * 2 * per * group)) || (rc = c->d_bnds.reserve(sizeof(int32_t) * 2 * row_max * group)) ||
+    if (pipe && ((rc = c->d_lprog.reserve(sizeof(int32_t) * static_cast<size_t>(group) * n_jobs * max_strips)) || (rc = c->d_lticket.reserve(64)))) return rc;
+    if ((rc = c->d_bndc.reserve(sizeof(float) * cost_rows * per * group)) || (rc = c->d_bnds.reserve(sizeof(int32_t) * 2 * row_max * group)) ||
         (rc = c->d_lbest.reserve(4 * n_part)) || (rc = c->d_lsecond.reserve(4 * n_part)) || (rc = c->d_lend.reserve(4 * n_part)) ||
         (rc = c->d_lwin.reserve(4 * 5 * static_cast<size_t>(n_long))) ||
         (rc = c->d_lck.reserve(sizeof(float) * std::max<int64_t>(ck_floats_per_read, 1) * group)))
@@ -347,6 +358,7 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.bnd_cost = c->d_bndc.as<float>();
         sa.bnd_start = c->d_bnds.as<int32_t>();
         sa.bnd_row_max = row_max;
+        sa.bnd_stride = cost_rows * per;
         sa.p_best = c->d_lbest.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_second = c->d_lsecond.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_end = c->d_lend.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
@@ -383,10 +395,29 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         fa.n_jobs = n_jobs;
         const dim3 block(256), fgrid((gn + 63) / 64), fblock(64);
         const dim3 grid1(static_cast<unsigned>((static_cast<int64_t>(gn) * n_jobs + 3) / 4)), grid2((gn + 3) / 4);
-        if (std_dtw)
+        if (pipe) {  // one wave per (job, read, strip), tickets in that order
+            int32_t *soff = reinterpret_cast<int32_t *>(hs + o_soff);
+            soff[0] = 0;
+            for (int32_t i = 0; i < gn; ++i) soff[i + 1] = soff[i] + n_strips_of[g0 + i];
+            // (the staging area was uploaded before the loop; this group's prefix sums go up on their own, stream-ordered)
+            HIP_TRY(hipStreamSynchronize(st));  // the previous group may still be reading its copy
+            HIP_TRY(hipMemcpyAsync(const_cast<char *>(ds) + o_soff, soff, sizeof(int32_t) * (gn + 1), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(c->d_lprog.p, 0, sizeof(int32_t) * static_cast<size_t>(gn) * n_jobs * max_strips, st));
+            HIP_TRY(hipMemsetAsync(c->d_lticket.p, 0, 4, st));
+            sa.strip_off = reinterpret_cast<const int32_t *>(ds + o_soff);
+            sa.progress = c->d_lprog.as<int32_t>();
+            sa.ticket = c->d_lticket.as<unsigned>();
+            const int64_t waves = static_cast<int64_t>(soff[gn]) * n_jobs;
+            const dim3 gridp(static_cast<unsigned>((waves + 3) / 4));
+            if (std_dtw)
+                hipLaunchKernelGGL((sfa::sdtw_strip_pipe_kernel<true>), gridp, block, 0, st, sa);
+            else
+                hipLaunchKernelGGL((sfa::sdtw_strip_pipe_kernel<false>), gridp, block, 0, st, sa);
+        } else if (std_dtw) {
             hipLaunchKernelGGL((sfa::sdtw_strip_kernel<true, false>), grid1, block, 0, st, sa);
-        else
+        } else {
             hipLaunchKernelGGL((sfa::sdtw_strip_kernel<false, false>), grid1, block, 0, st, sa);
+        }
         KERNEL_TRY();
         fa.mode = 1;
         hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, fgrid, fblock, 0, st, fa);
@@ -496,6 +527,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         return rc;
     if ((rc = c->d_wchunk.reserve(4 * static_cast<size_t>(n)))) return rc;
     const bool fused = plan.lds_ckpt && c->opt_fused_trace;
+    if (fused && (rc = c->d_args.reserve(sizeof(DpArgs)))) return rc;
     if (fused && ((rc = c->d_ticket.reserve(64)) || (rc = c->d_quaddone.reserve(4 * static_cast<size_t>(std::max(n_quads, 1)))))) return rc;
     if (plan.lds_ckpt && ((rc = c->d_bestrec.reserve(sizeof(float) * sfa::kLdsCkPlanes * 64 * n_part / 4)) || (rc = c->d_beste.reserve(4 * n_part)) ||
                           (rc = c->d_gbest.reserve(4 * static_cast<size_t>(n)))))
@@ -618,6 +650,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
                 fz.mode = 3;  // rows of the reads in no quad; every other row is written by the launch's pass-2 waves
                 hipLaunchKernelGGL(sfa::sdtw_finalize_kernel, fgrid, fblock, 0, st, fz);
                 KERNEL_TRY();
+                da.self = c->d_args.as<DpArgs>();
+                HIP_TRY(hipMemcpyAsync(c->d_args.p, &da, sizeof(DpArgs), hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
                 launch_fill_fused(plan.max_R, da, st);
             } else {
                 launch_fill_lck(plan.max_R, da, st);
@@ -665,7 +699,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     c->long_pending = !long_reads.empty();
     if (c->long_pending) {
         HIP_TRY(hipEventRecord(c->ev[5], st));
-        if ((rc = align_long(c, d_queries, da.q_off, long_reads, long_max, d_out))) return rc;
+        if ((rc = align_long(c, d_queries, da.q_off, q_off, long_reads, long_max, d_out))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[4], st));
@@ -935,7 +969,7 @@ void sfa_destroy(sfa_ctx_t *c) {
                       &c->d_queries, &c->d_stage, &c->d_pbest, &c->d_pend, &c->d_pst, &c->d_pjob, &c->d_psecond, &c->d_wjob,
                       &c->d_wend, &c->d_wscore, &c->d_tst, &c->d_ck, &c->d_out, &c->e_raw, &c->e_rawoff, &c->e_scale, &c->e_sum,
                       &c->e_sumsq, &c->e_t1, &c->e_t2, &c->e_evoff, &c->e_evstart, &c->e_evlen, &c->e_evmean, &c->e_evstdv, &c->e_nev,
-                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount, &c->d_bestrec, &c->d_beste, &c->d_gbest, &c->d_wchunk, &c->d_ticket, &c->d_quaddone, &c->b_in, &c->b_inoff, &c->b_out, &c->b_outoff, &c->b_len, &c->b_head, &c->b_bad})
+                      &c->e_qstart, &c->e_qoff, &c->e_b0, &c->e_b1, &c->e_b2, &c->e_flag, &c->e_qev, &c->e_pflag, &c->d_verify, &c->d_segfail, &c->d_bndc, &c->d_bnds, &c->d_long, &c->d_lbest, &c->d_lsecond, &c->d_lend, &c->d_lwin, &c->d_lck, &c->d_lprog, &c->d_lticket, &c->d_times, &c->d_started, &c->d_bad, &c->d_badcount, &c->d_bestrec, &c->d_beste, &c->d_gbest, &c->d_wchunk, &c->d_ticket, &c->d_quaddone, &c->d_args, &c->b_in, &c->b_inoff, &c->b_out, &c->b_outoff, &c->b_len, &c->b_head, &c->b_bad})
         b->release();
     c->h_stage.release();
     c->h_out.release();
@@ -991,6 +1025,8 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "widen_below") {
         if (value < 0) return fail(SFA_EINVAL, "widen_below must be >= 0");
         c->opt_widen_below = value;
+    } else if (k == "strip_pipeline") {
+        c->opt_strip_pipeline = value != 0;
     } else if (k == "fused_trace") {
         c->opt_fused_trace = value != 0;
     } else if (k == "lds_ckpt") {

@@ -36,6 +36,7 @@ MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "la
          "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1}, "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2},
          "lds_wide4_backoff": {"trace_margin": 0, "lane_widening": 4, "column_segments": 1, "lds_ckpt": 2},
          "lds_unfused": {"lds_ckpt": 2, "fused_trace": 0, "lane_widening": 1},
+         "classic_strips": {"strip_pipeline": 0},  # row strips: one wave per (read, job) instead of one per strip
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
          "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
          "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}
@@ -144,7 +145,7 @@ def test_long_queries(oracle, seed, mode, gpu_mode):
     assert_rows_equal(got, want)
 
 
-@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto"])
+@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto", "classic_strips"])
 @pytest.mark.parametrize("seed", range(4))
 @pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
 def test_row_strips(oracle, seed, mode, gpu_mode):
@@ -199,6 +200,8 @@ def test_row_strips_ncov_and_groups(oracle):
         al.set_option("ckpt_budget_bytes", 1 << 20)  # less than one read's boundary rows: groups of one read
         assert al.align_db(q, q_off).tobytes() == got.tobytes()
         assert al.profile()["fill_launches"] == 1 + 3
+        al.set_option("strip_pipeline", 0)  # one wave per (read, job)
+        assert al.align_db(q, q_off).tobytes() == got.tobytes()
 
 
 def test_row_strips_extreme_lengths(oracle):
