@@ -300,8 +300,12 @@ static int dtw_run(int argc, char **argv) {
     }
 
     // ---- init_core(), src/sigfish.c:81-207 ----
+    double t_init[4] = {0, 0, 0, 0};  // reader, model + reference events, device contexts, (teardown)
+    double ti = realtime();
     sfa::Blow5Reader reader;
     if (!reader.open(blow5)) die(reader.error());
+    t_init[0] = realtime() - ti;
+    ti = realtime();
     if (const char *exp = reader.attr("experiment_type")) {
         if (!strcmp(exp, "rna")) o.flag |= F_RNA;
     }
@@ -343,6 +347,8 @@ static int dtw_run(int argc, char **argv) {
         rp[i] = rna ? nullptr : rev[i].data();
     }
     sfa_ref_t sref{nref, ref_len.data(), ref_off.data(), fp.data(), rna ? nullptr : rp.data()};
+    t_init[1] = realtime() - ti;
+    ti = realtime();
     // two contexts (streams + scratch) on the same device: consecutive batches alternate between them, so the uploads
     // and the event detection of batch i+1 overlap the DTW of batch i
     // (--streams: more than two were measured to add nothing, the stages of one batch already serialise on syncs)
@@ -364,6 +370,11 @@ static int dtw_run(int argc, char **argv) {
         const int per_dev = n_ctx / static_cast<int>(o.devices.size());
         if (sfa_set_option(ctxs[j], "widen_below", std::max(1, 5 / per_dev)) != SFA_OK) die(sfa_last_error());
     }
+
+    t_init[2] = realtime() - ti;
+    if (o.verbosity >= 4)
+        fprintf(stderr, "[dtw_main::%.3f] initialised: input %.3f s, model + reference events %.3f s, %d device context(s) %.3f s\n", realtime() - t0,
+                t_init[0], t_init[1], n_ctx, t_init[2]);
 
     if (o.flag & F_SAM) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
         for (int32_t i = 0; i < nref; ++i) fprintf(stdout, "@SQ\tSN:%s\tLN:%ld\n", contigs[i].name.c_str(), static_cast<long>(ref_len[i]));
@@ -696,6 +707,7 @@ static int dtw_run(int argc, char **argv) {
                 t_proc, t_dtw);
         fprintf(stderr, "[dtw_main] Data output time: %.3f sec\n", t_out);
     }
+    if (o.verbosity >= 4) fprintf(stderr, "[dtw_main::%.3f] all output written; releasing the device\n", realtime() - t0);
     return 0;
 }
 

@@ -476,12 +476,21 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             if (e >= ck_next) {
                 lck->template snapshot<R>(cv, dprev, e);
                 ck_next += 1 << kLdsCkShift;
-                // every coarse_every-th one also goes to the sparse HBM store (what pass 2 backs off to), same format as below
+                // every coarse_every-th one also goes to the sparse HBM store (what pass 2 backs off to), same format as below;
+                // write-through in the fused launch, whose pass 2 reads it in the same launch, possibly from another XCD (found by
+                // the fuzz campaign: a stale record there sent pass 2 off with a garbage step index)
                 if (T && (lck->count & (a.coarse_every - 1)) == 0 && (lck->count << kLdsCkShift) <= ck_last) {
+                    if (WT) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
-                    ckp[R * 64] = dprev;
-                    ckp[(R + 1) * 64] = __int_as_float(e);
+                        for (int r = 0; r < R; ++r) __hip_atomic_store(ckp + r * 64, static_cast<float>(cv[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(ckp + R * 64, dprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(ckp + (R + 1) * 64, __int_as_float(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
+                        ckp[R * 64] = dprev;
+                        ckp[(R + 1) * 64] = __int_as_float(e);
+                    }
                     ckp += ck_planes<R>() * 64;
                 }
             }
@@ -1102,14 +1111,17 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
         }
         // std_dtw(): a row that restarts at or before column 0 begins with the free boundary, later ones with +inf
         xc.template set_boundary<true>(lane0, (STD && tb > 0) ? INFINITY : 0.0f);
-        const int len = done ? 0 : (t_last - tb + 1);
+        // (a step index behind the window's first cell, or in front of the sweep's origin, cannot be this window's snapshot: the
+        // lane sits the attempt out -- from a harmless position -- and backs off)
+        const bool bad_rec = !done && (tb > t_first || tb < t_begin);
+        if (bad_rec) tb = t_begin;
+        const int len = (done || bad_rec) ? 0 : (t_last - tb + 1);
         int maxlen = __builtin_amdgcn_readlane(len, 0);
         if (L <= 32) maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 32));
         if (L <= 16) {
             maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 16));
             maxlen = max(maxlen, __builtin_amdgcn_readlane(len, 48));
         }
-        if (maxlen <= 0) break;
 
         // first cell of the window whose cost equals the winning score (= the first strict minimum the reference's
         // scan selects, src/sigfish.c:892-899), and the start column carried into it
@@ -1124,7 +1136,7 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
                 dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t, lane0, xc);
                 const float cl = c[rq];
                 const int sl = s[rq];
-                const bool hit = (cap_end < 0) && (t >= t_first) && (t <= t_last) && (cl == best);
+                const bool hit = (cap_end < 0) && !bad_rec && (t >= t_first) && (t <= t_last) && (cl == best);
                 cap_end = hit ? (t - lq) : cap_end;
                 cap_st = hit ? sl : cap_st;
             }

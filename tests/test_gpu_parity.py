@@ -491,6 +491,27 @@ def test_degenerate_and_non_finite_queries_against_the_reference():
         assert list(np.flatnonzero(got["valid"] == 0)) == list(z["non_finite"])
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_backoff_to_the_sparse_checkpoints_inside_the_fused_launch(oracle, fused):
+    """A strand long enough for the sparse HBM checkpoints behind the LDS ones (every 32 768 steps) and no head start at all for
+    pass 2 (trace_margin 0): most winners beyond column 32 768 start pass 2 from the saved snapshot, fail, and back off to
+    the sparse store -- which, in the fused launch, another XCD wrote during the same launch.  (Found by the fuzz campaign
+    while those stores were not yet write-through: seed 2026, iteration 8414.)"""
+    rng = np.random.default_rng(8414)
+    ref = _small_ref(rng, [70000], True, quant=True)
+    qlens = rng.integers(20, 257, size=120)
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = (rng.integers(-8, 9, int(q_off[-1])) / 4).astype(np.float32)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), S.RNA | S.INV, threads=8)
+    assert (want["pos_end"] > 33000).sum() > 20
+    with S.Aligner(ref, S.RNA | S.INV) as al:
+        for k, v in (("trace_margin", 0), ("lane_widening", 1), ("lds_ckpt", 2), ("fused_trace", fused), ("prio_unit", 64)):
+            al.set_option(k, v)
+        for _ in range(3):
+            assert_rows_equal(al.align_db(q, q_off), want)
+        assert al.profile()["lds_ckpt"] == (2 if fused else 1)
+
+
 def test_non_finite_long_query_is_skipped_too():
     """The same screen in front of the row-strip path (queries beyond 2048 events)."""
     rng = np.random.default_rng(5)
