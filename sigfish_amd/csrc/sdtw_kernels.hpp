@@ -55,6 +55,12 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #ifndef SFA_LCK_WAVES
 #define SFA_LCK_WAVES 4  // the fill with its checkpoints in LDS: 2 x 17 planes x 256 B per wave -> four blocks of four waves per CU
 #endif
+#ifndef SFA_FUSED_PERSIST
+#define SFA_FUSED_PERSIST 0  // fused launch: 1 = a wave that has finished its ticket claims the next one itself; 0 = one ticket per wave.
+                             // Measured level (profiles/r02_logs/ab_fused_persistent_waves.log): by the time pass-2 tickets come up the
+                             // fill's tail is already packed by the issue priority, the step is fill work + pass-2 work either way
+
+#endif
 #ifndef SFA_TRACE_WAVES
 #define SFA_TRACE_WAVES 4  // waves per SIMD pass 2 (R <= 16) is register-budgeted for: 128 VGPRs; 3.49 -> 3.28 ms per 100 k reads against 144 VGPRs / 3 waves
 #endif
@@ -941,21 +947,25 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[(TRACK || FUSED) ? 4 * kXchWordsPerWave : 1];
     __shared__ float lds_ck[LCK ? 4 * 2 * kLdsCkPlanes * 64 : 1];
-    if (FUSED) {
-        unsigned t = 0;
-        if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        task = __builtin_amdgcn_readfirstlane(t);
-        if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
-            const int quad = task - a.n_tasks;
-            if (quad < a.n_quads_total) fused_trace_dispatch<MAXR>(a.self, quad, lds_f, lds_i);
-            return;
+    // FUSED with SFA_FUSED_PERSIST: a wave works through tickets until they run out instead of leaving its slot to a new block
+    for (;;) {
+        if (FUSED) {
+            unsigned t = 0;
+            if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            task = __builtin_amdgcn_readfirstlane(t);
+            if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
+                const int quad = task - a.n_tasks;
+                if (quad >= a.n_quads_total) return;
+                fused_trace_dispatch<MAXR>(a.self, quad, lds_f, lds_i);
+                if (SFA_FUSED_PERSIST) continue;
+                return;
+            }
         }
-    }
-    if (task >= a.n_tasks) return;  // wave-uniform
-    int ci = 0;
-    while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
-    const ClassDesc cd = a.cls[ci];
-    const int tl = task - cd.task_base;
+        if (task >= a.n_tasks) return;  // wave-uniform
+        int ci = 0;
+        while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
+        const ClassDesc cd = a.cls[ci];
+        const int tl = task - cd.task_base;
 #define SFA_SHAPE(RR, LL)                                                                    \
     case (RR) * 256 + (LL):                                                                  \
         if constexpr (MAXR >= (RR)) {                                                        \
@@ -965,16 +975,18 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
                 fill_body<RR, LL, TRACK, STD, LCK, FUSED>(a, cd, tl, lds_f, lds_i, lds_ck);  \
         }                                                                                    \
         break;
-    switch (cd.R * 256 + cd.lanes) {
-        SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
-        SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
-        SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
-        SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
-        SFA_SHAPE(4, 16)
-        default:
-            break;
-    }
+        switch (cd.R * 256 + cd.lanes) {
+            SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
+            SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
+            SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
+            SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
+            SFA_SHAPE(4, 16)
+            default:
+                break;
+        }
 #undef SFA_SHAPE
+        if (!(FUSED && SFA_FUSED_PERSIST)) return;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -256,8 +256,14 @@ void launch_fill_lck(int maxr, const DpArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, false, true>), grid, block, 0, st, a);
 }
 
-void launch_fill_fused(int maxr, const DpArgs &a, hipStream_t st) {  // fill tasks + one pass-2 ticket per quad
-    const dim3 grid((a.n_tasks + 3) / 4 + (a.n_quads_total + 3) / 4), block(256);
+void launch_fill_fused(int maxr, const DpArgs &a, hipStream_t st, int cu_count) {  // fill tasks + one pass-2 ticket per quad
+    // waves claim tickets until they run out: no more blocks than the device holds at once (four per CU: the LDS buffers), so
+    // that none of them starts only to find the counter exhausted
+    unsigned blocks = static_cast<unsigned>((a.n_tasks + 3) / 4 + (a.n_quads_total + 3) / 4);
+#if SFA_FUSED_PERSIST
+    blocks = std::min<unsigned>(blocks, static_cast<unsigned>(cu_count) * SFA_LCK_WAVES);
+#endif
+    const dim3 grid(blocks), block(256);
     if (maxr >= 16)
         hipLaunchKernelGGL((sfa::sdtw_fill_kernel<16, false, false, false, true, true>), grid, block, 0, st, a);
     else if (maxr >= 8)
@@ -652,7 +658,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
                 KERNEL_TRY();
                 da.self = c->d_args.as<DpArgs>();
                 HIP_TRY(hipMemcpyAsync(c->d_args.p, &da, sizeof(DpArgs), hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
-                launch_fill_fused(plan.max_R, da, st);
+                launch_fill_fused(plan.max_R, da, st, c->cu_count);
             } else {
                 launch_fill_lck(plan.max_R, da, st);
             }
