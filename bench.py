@@ -110,6 +110,8 @@ def main():
     # torch's is initialised FIRST.  Do not rely on import order: check it.
     assert torch.cuda.is_initialized(), "torch.cuda must be initialised before libsigfish_amd.so makes its first HIP call"
     force_dist = os.environ.get("SFA_DIST_FORCE") == "1"  # rehearse the RCCL path with one rank
+    if force_dist and not launch.launched_by_a_launcher():  # a bare `python bench.py`: be our own one-rank launcher
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
     if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=dev)
 

@@ -1250,7 +1250,7 @@ __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDes
     const int slot = lane / L;
     // every fill task of the quad must have published its results (they hold lower tickets: running or finished)
     if (lane == 0) {
-        while (__hip_atomic_load(a.quad_done + quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_chunks) __builtin_amdgcn_s_sleep(32);
+        while (__hip_atomic_load(a.quad_done + quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_chunks) __builtin_amdgcn_s_sleep(127);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __builtin_amdgcn_wave_barrier();

@@ -532,7 +532,11 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         (rc = c->d_tst.reserve(8 * (size_t)n)) || (rc = c->d_wscore.reserve(4 * (size_t)n)))
         return rc;
     if ((rc = c->d_wchunk.reserve(4 * static_cast<size_t>(n)))) return rc;
-    const bool fused = plan.lds_ckpt && c->opt_fused_trace;
+    // pass 2 inside the fill launch pays when the launch has more tasks than wave slots: its tickets then come up as the fill
+    // drains.  With everything resident from the start the pass-2 waves would only sit next to the fill waves and poll
+    // (measured: 2 048 reads 2.9 -> 3.3 ms per batch), so small launches keep the separate pass-2 launch.
+    const bool fused = plan.lds_ckpt && c->opt_fused_trace &&
+                       (c->opt_fused_trace > 1 || static_cast<int64_t>(n_quads) * n_chunks > static_cast<int64_t>(c->cu_count) * 4 * SFA_LCK_WAVES);
     if (fused && (rc = c->d_args.reserve(sizeof(DpArgs)))) return rc;
     if (fused && ((rc = c->d_ticket.reserve(64)) || (rc = c->d_quaddone.reserve(4 * static_cast<size_t>(std::max(n_quads, 1)))))) return rc;
     if (plan.lds_ckpt && ((rc = c->d_bestrec.reserve(sizeof(float) * sfa::kLdsCkPlanes * 64 * n_part / 4)) || (rc = c->d_beste.reserve(4 * n_part)) ||
@@ -1034,7 +1038,8 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "strip_pipeline") {
         c->opt_strip_pipeline = value != 0;
     } else if (k == "fused_trace") {
-        c->opt_fused_trace = value != 0;
+        if (value < 0 || value > 2) return fail(SFA_EINVAL, "fused_trace must be 0 (off), 1 (launches with more tasks than wave slots) or 2 (always)");
+        c->opt_fused_trace = value;
     } else if (k == "lds_ckpt") {
         if (value < 0 || value > 2) return fail(SFA_EINVAL, "lds_ckpt must be 0 (off), 1 (where shapes and batch size suit) or 2 (wherever the shapes allow)");
         c->opt_lds_ckpt = value;

@@ -33,8 +33,9 @@ def assert_rows_equal(got, want):
 # "hbm_ckpt": every snapshot of pass 1 in HBM (the round-1 scheme; the default now keeps them in LDS where the shapes allow);
 # "lds_backoff": LDS checkpoints with no head start at all, so that pass 2 must back off to the sparse store / the strand start
 MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "lane_widening": 1},
-         "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1}, "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2},
-         "lds_wide4_backoff": {"trace_margin": 0, "lane_widening": 4, "column_segments": 1, "lds_ckpt": 2},
+         "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1}, "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2, "fused_trace": 2},
+         "lds_wide4_backoff": {"trace_margin": 0, "lane_widening": 4, "column_segments": 1, "lds_ckpt": 2, "fused_trace": 2},
+         "lds_fused": {"lds_ckpt": 2, "fused_trace": 2, "lane_widening": 1},
          "lds_unfused": {"lds_ckpt": 2, "fused_trace": 0, "lane_widening": 1},
          "classic_strips": {"strip_pipeline": 0},  # row strips: one wave per (read, job) instead of one per strip
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
@@ -505,7 +506,7 @@ def test_backoff_to_the_sparse_checkpoints_inside_the_fused_launch(oracle, fused
     want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), S.RNA | S.INV, threads=8)
     assert (want["pos_end"] > 33000).sum() > 20
     with S.Aligner(ref, S.RNA | S.INV) as al:
-        for k, v in (("trace_margin", 0), ("lane_widening", 1), ("lds_ckpt", 2), ("fused_trace", fused), ("prio_unit", 64)):
+        for k, v in (("trace_margin", 0), ("lane_widening", 1), ("lds_ckpt", 2), ("fused_trace", 2 * fused), ("prio_unit", 64)):
             al.set_option(k, v)
         for _ in range(3):
             assert_rows_equal(al.align_db(q, q_off), want)
