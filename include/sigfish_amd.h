@@ -172,7 +172,8 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
  * the fill's longest-remaining-first issue priority in the tail of a launch; 0 = off), "fused_trace" (with "lds_ckpt": 1 =
  * default: pass 2 runs inside the fill launch when the launch has more wave-tasks than the device has wave slots, 2 =
  * always, 0 = always as its own launch), "strip_pipeline" (long queries: 1 = default, the row strips of pass 1 run as one
- * pipelined launch; 0 = one launch per strip),
+ * pipelined launch; 0 = one wave per (read, contig, strand)), "strip_chain" (long queries: 1 = default, pass 2 traces the
+ * strips from the last one upwards, each over its own short range of columns; 0 = all strips over the whole range),
  * "waves_per_simd" (1..8, occupancy target used when splitting the contig list), "lane_widening" (0 = auto by batch
  * size, 1/2/4 = fixed: rows per lane / w and lanes per read * w, the small-batch latency shapes), "widen_below"
  * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 5), "min_slice_reads" (a batch whose

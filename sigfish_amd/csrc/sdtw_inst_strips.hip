@@ -5,6 +5,8 @@ template __global__ void sdtw_strip_kernel<false, false>(const StripArgs);
 template __global__ void sdtw_strip_kernel<true, false>(const StripArgs);
 template __global__ void sdtw_strip_kernel<false, true>(const StripArgs);
 template __global__ void sdtw_strip_kernel<true, true>(const StripArgs);
+template __global__ void sdtw_strip_chain_kernel<false>(const StripArgs);
+template __global__ void sdtw_strip_chain_kernel<true>(const StripArgs);
 template __global__ void sdtw_strip_pipe_kernel<false>(const StripArgs);
 template __global__ void sdtw_strip_pipe_kernel<true>(const StripArgs);
 }  // namespace sfa

@@ -1198,6 +1198,8 @@ struct FinalizeArgs {
     const int32_t *t_st;  // two-pass, second finalize: start columns [n_reads] then end columns [n_reads] from the trace kernel
     ResultRow *out;       // [n_reads]
     const uint8_t *bad;   // [n_reads] 1: a query value is NaN or +-inf (sdtw_screen_kernel) -> the read is skipped
+    const int64_t *q_off;  // [n_reads+1]; with max_query: a longer read belongs to the row-strip path (sdtw_strips.hpp), which
+    int32_t max_query;     // writes its row from another stream -- no row is written for it here (0: every row is written)
     int32_t n_reads, n_chunks;
     int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions;
                    // 3: fused launch -> rows of the reads that are in no quad (skipped), the rest is written by its pass-2 waves
@@ -1391,6 +1393,8 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_reads) return;
     const int sl = a.slot_of_read[i];
+    const bool strips = a.max_query > 0 && a.q_off[i + 1] - a.q_off[i] > a.max_query;
+    if (strips && a.mode != 1) return;
     if (a.mode == 3) {  // fused launch: its pass-2 waves write the rows of every read they handle; the others are skipped reads
         if (sl >= 0) return;
         ResultRow r;
@@ -1474,7 +1478,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
         a.w_score[i] = r.score;
         a.w_chunk[i] = wchunk;
     }
-    a.out[i] = r;
+    if (!strips) a.out[i] = r;
 }
 #endif
 

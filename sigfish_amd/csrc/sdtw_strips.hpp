@@ -63,19 +63,28 @@ struct StripArgs {
     const int32_t *strip_off;   // [n_long+1] prefix sum of the reads' strip counts
     int32_t *progress;          // [n_long][n_jobs][max_strips] columns of the strip's last row that are complete and visible
     unsigned *ticket;           // task counter (zeroed before the launch)
+    int32_t keep_rows;          // classic pass 1: 1 = strip s writes boundary row s (bnd_stride rows per read) instead of two rows in turn
 };
 
-constexpr int kPipeBlock = 1024;  // columns between two hand-overs of a boundary row (one release / acquire pair each)
+#ifndef SFA_PIPE_BLOCK
+#define SFA_PIPE_BLOCK 512
+#endif
+constexpr int kPipeBlock = SFA_PIPE_BLOCK;  // columns between two hand-overs of a boundary row (one release / acquire pair each)
 
 // One anti-diagonal step of a strip: dp_step<32, TRACK> with the handling of query row 0 made conditional on FIRST (the
 // strip that contains it).
 template <bool STD, bool FIRST, bool TRACK>
 __device__ __forceinline__ void strip_step(typename Vec<float, kStripR>::type &c, typename Vec<int, kStripR>::type &s, float &dprev,
                                            int &sdprev, const float (&x)[kStripR], const float yv, const int t, const bool lane0,
-                                           Exchange &xc) {
+                                           Exchange &xc, const float bup = 0.0f, const int bsup = 0) {
+    // bup / bsup (wave-uniform; strips below the first): the cell above lane 0's first row, from the boundary row in HBM
     float up = xc.shift(static_cast<float>(c[kStripR - 1]));
     int sup = 0;
     if (TRACK) sup = xc.shift(static_cast<int>(s[kStripR - 1]));
+    if (!FIRST) {
+        up = lane0 ? bup : up;
+        if (TRACK) sup = lane0 ? bsup : sup;
+    }
     if (STD && FIRST) {
         if (t == 0) xc.template set_boundary<TRACK>(lane0, INFINITY);  // std_dtw(): row 0 continues from its left neighbour only
     }
@@ -110,12 +119,26 @@ __device__ __forceinline__ void strip_step(typename Vec<float, kStripR>::type &c
     }
 }
 
-struct __attribute__((aligned(16))) int4a {
-    int v[4];
-};
-struct __attribute__((aligned(16))) float4a {
-    float v[4];
-};
+// Four columns of a boundary row.  `through`: the row is handed to another wave of the same launch (pipelined pass 1), maybe
+// on another XCD with its own L2: the store writes through to memory (sc1), so that the producer only has to wait for its own
+// stores (publish_fence) instead of writing back the whole L2 (a release fence at agent scope is buffer_wbl2 -- with 17 GB of
+// checkpoints passing through the same L2, once per kPipeBlock columns and wave).
+#ifndef SFA_STRIP_WT
+#define SFA_STRIP_WT 1
+#endif
+__device__ __forceinline__ void store_row4(float *p, const typename Vec<float, 4>::type v, const bool through) {
+    if (SFA_STRIP_WT && through)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else
+        *reinterpret_cast<typename Vec<float, 4>::type *>(p) = v;
+}
+__device__ __forceinline__ void publish_fence() {
+    if (SFA_STRIP_WT)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): this wave's write-through stores are in memory
+    else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+
 
 // What the final strip reports.  Pass 1: the running top-2 over windows (by window).  Pass 2: the winning cell.
 struct StripResult {
@@ -125,7 +148,7 @@ struct StripResult {
 
 // One strip over columns [0, ncols) of one (contig,strand).  `last`: the strip holds the last query row (lane lq,
 // register rq).  Pass 2 (TRACK): [ws, ncols) is the winning window and `best` its minimum.
-template <bool STD, bool FIRST, bool TRACK>
+template <bool STD, bool FIRST, bool TRACK, bool CHAIN = false>
 __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen, const bool last,
                                             const float (&x)[kStripR], const int lq, const int rq, const int lane, Exchange &xc,
                                             const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
@@ -147,7 +170,7 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             s[r] = -1;
         }
         dprev = rec[kStripR * 64];
-        sdprev = -1;
+        sdprev = (CHAIN && !FIRST && lane == 0) ? t_begin - 1 : -1;  // lane 0's diagonal input is the row above, column t_begin - 1
     } else {
 #pragma unroll
         for (int r = 0; r < kStripR; ++r) {
@@ -169,13 +192,16 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     int wpos = -1;
     int wend = min(qlen, rlen);
 
-    const int n_steps = ncols + lq;  // lane lq meets column ncols - 1 at step ncols - 1 + lq
-    // hand-over of the boundary row in blocks of kPipeBlock columns.  The consumer reads one block of four columns ahead, the
-    // producer's lane 63 writes column t - 63 at step t: before a consumer enters steps [t0, t0 + kPipeBlock) it wants columns
-    // below t0 + kPipeBlock + 8; at the top of its block t0 a producer has completed the columns below t0 - 64.
+    // lane lq meets column ncols - 1 at step ncols - 1 + lq; pass 1 stores a boundary row four columns at a time, the last
+    // group is complete up to three steps later (columns past ncols - 1 land in the pad behind the row)
+    const int n_steps = ncols + lq + ((!TRACK && !last) ? 4 : 0);
+    typename Vec<float, 4>::type ob = {0.0f, 0.0f, 0.0f, 0.0f};
+    // hand-over of the boundary row in blocks of kPipeBlock columns (a multiple of the 64-column chunk).  The consumer loads a
+    // chunk one chunk ahead -- inside steps [t0, t0 + kPipeBlock) it touches the columns below t0 + kPipeBlock + 64 --, the
+    // producer's lane 63 has stored the columns below t0 - 64 at the top of its block t0.
     int wait_next = t_begin, pub_next = t_begin + kPipeBlock;
     auto wait_for_row = [&](int t0) {
-        const int need = min(ncols, t0 + kPipeBlock + 8);
+        const int need = min(ncols, t0 + kPipeBlock + 72);
         if (lane == 0)
             while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
         __builtin_amdgcn_wave_barrier();
@@ -184,17 +210,20 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     };
     if (!FIRST && prog_in) wait_for_row(t_begin);
     float4u ycur = *reinterpret_cast<const float4u *>(yp + t_begin);
-    float4a bc{};
-    int4a bs{};
+    // The row above, 64 columns at a time: lane l holds column (chunk base) + l, the next chunk is in flight while this one is
+    // used (64 steps: a boundary row another wave has just written through comes from HBM, not from this XCD's L2), and
+    // every step picks its column with v_readlane.
+    float bcur = 0.0f, bnxt = 0.0f;
+    int scur = 0, snxt = 0;
     if (!FIRST) {
-        bc = *reinterpret_cast<const float4a *>(bin_c + t_begin);
-        if (TRACK) bs = *reinterpret_cast<const int4a *>(bin_s + t_begin);
+        bnxt = bin_c[t_begin + lane];
+        if (TRACK && !CHAIN) snxt = bin_s[t_begin + lane];
     }
     for (int t0 = t_begin; t0 < n_steps; t0 += 4) {
         if (!TRACK) {
             if (!FIRST && prog_in && t0 >= wait_next) wait_for_row(t0);
-            if (prog_out && t0 >= pub_next) {  // the stores of the columns below t0 - 64 become visible, then the counter says so
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (prog_out && t0 >= pub_next) {  // the stores of the columns below t0 - 64 have reached memory, then the counter says so
+                publish_fence();
                 if (lane == 0) __hip_atomic_store(prog_out, t0 - 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pub_next = t0 + kPipeBlock;
             }
@@ -206,32 +235,41 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             }
         }
         const float4u ynext = *reinterpret_cast<const float4u *>(yp + t0 + 4);
-        float4a bcn{};
-        int4a bsn{};
-        if (!FIRST) {
+        const int cpos = (t0 - t_begin) & 63;  // wave-uniform: position of step t0 inside the chunk
+        if (!FIRST && cpos == 0) {
             // Past column ncols - 1 (up to kBndPad words) this reads words nobody wrote for this read and job: left-overs
             // of an earlier sweep, or the fill pattern of the allocation.  They only ever reach cells of columns >= ncols,
             // and every cell depends on cells of its own or a LOWER column alone (up, diagonal, left) -- nothing of a
             // column < ncols, the only ones that are read out, can see them.  (align_long() fills fresh allocations with
             // a large finite pattern so that tools inspecting the buffers see no NaNs; correctness does not rest on it.)
-            bcn = *reinterpret_cast<const float4a *>(bin_c + t0 + 4);
-            if (TRACK) bsn = *reinterpret_cast<const int4a *>(bin_s + t0 + 4);
+            bcur = bnxt;
+            bnxt = bin_c[t0 + 64 + lane];
+            if (TRACK && !CHAIN) {
+                scur = snxt;
+                snxt = bin_s[t0 + 64 + lane];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u;
+            float bup = 0.0f;
+            int bsup = 0;
             if (!FIRST) {  // the row above query row 0 of this strip: column t of the previous strip's last row
-                if (lane0) {
-                    *((Exchange::lds_vf *)xc.rf) = bc.v[u];
-                    if (TRACK) *((Exchange::lds_vi *)xc.ri) = bs.v[u];
-                }
+                bup = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcur), cpos + u));
+                // CHAIN: what is carried is the COLUMN of the row above through which the path enters this strip
+                if (TRACK) bsup = CHAIN ? t : __builtin_amdgcn_readlane(scur, cpos + u);
             }
-            strip_step<STD, FIRST, TRACK>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc);
-            if (!last) {  // (wave-uniform) lane 63 is at column t - 63 of the strip's last row
+            strip_step<STD, FIRST, TRACK>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc, bup, bsup);
+            if (!CHAIN && !last && !TRACK) {
+                // (wave-uniform) lane 63 is at column t - 63 of the strip's last row; t0 is a multiple of 4, so the column is
+                // u + 1 (mod 4): four columns are collected and stored as one aligned 16-byte word when the fourth arrives
+                ob[(u + 1) & 3] = c[kStripR - 1];
+                if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob, prog_out != nullptr);
+            } else if (!CHAIN && !last) {
                 const int col = t - 63;
                 if (lane == 63 && col >= 0 && col < ncols) {
                     bout_c[col] = c[kStripR - 1];
-                    if (TRACK) bout_s[col] = s[kStripR - 1];
+                    bout_s[col] = s[kStripR - 1];
                 }
             } else {
                 const int col = t - lq;  // wave-uniform
@@ -258,11 +296,9 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             }
         }
         ycur = ynext;
-        bc = bcn;
-        bs = bsn;
     }
     if (!TRACK && prog_out) {  // the whole row is there
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        publish_fence();
         if (lane == 0) __hip_atomic_store(prog_out, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -333,8 +369,9 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
                 const int src = a.rev_query ? (qlen - 1 - i) : i;
                 x[r] = (i < qlen) ? q[src] : 0.0f;
             }
-            float *bout_c = bc + (sidx & 1) * per;
-            const float *bin_c = bc + ((sidx & 1) ^ 1) * per;
+            // two rows in turn, or (pass 1 with the chained pass 2 behind it) one row per strip boundary, kept
+            float *bout_c = bc + ((!TRACK && a.keep_rows) ? sidx : (sidx & 1)) * per;
+            const float *bin_c = bc + ((!TRACK && a.keep_rows) ? sidx - 1 : ((sidx & 1) ^ 1)) * per;
             int32_t *bout_s = TRACK ? bs + (sidx & 1) * a.bnd_row_max : nullptr;
             const int32_t *bin_s = TRACK ? bs + ((sidx & 1) ^ 1) * a.bnd_row_max : nullptr;
             float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
@@ -377,7 +414,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
 // deadlock whatever order the hardware starts blocks in.  Everything else (checkpoints per strip, window scan in the final
 // strip, partial top-2 per (read, job)) is the classic pass 1's.
 template <bool STD>
-__global__ void __launch_bounds__(256, 2) sdtw_strip_pipe_kernel(const StripArgs a) {
+__global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs a) {
     const int lane = threadIdx.x & 63;
     unsigned t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -445,7 +482,102 @@ __global__ void __launch_bounds__(256, 2) sdtw_strip_pipe_kernel(const StripArgs
     }
 }
 
+
+// Pass 2, CHAINED (one wave per long read, its winning job): the strips are traced from the LAST one upwards, each over its own
+// short range of columns.  Pass 1 kept the last row of every strip (one row per strip boundary), so a strip can be swept on
+// its own: its `row above` is the row pass 1 stored.  What a strip carries is not the start of the whole path but the column b
+// of the row above through which the path ENTERS the strip: a cell of the strip's first row that continues diagonally from
+// column j - 1 or upwards from column j of the row above takes b = j - 1 or j (lane 0's `up` input carries its own column;
+// its diagonal input is the previous step's); every other cell inherits b by the traceback rule of path()
+// (src/cdtw.c:134-146), exactly as the start column is inherited in the unchained pass 2.  The rule is local, so the cells
+// (last row of strip s - 1, b_s) are the cells of the reference's path, and strip 0 -- which holds query row 0 -- delivers the
+// start column.  The cell a strip has to reach is known by column AND cost (the winning score for the last strip, the stored
+// row's value for the others), compared bit for bit: a difference between the passes cannot go unnoticed.
+// A strip of r rows is swept from the checkpoint r + 64 columns (or `trace_margin`) in front of its target cell and backs off
+// 1, 2, 4 ... checkpoints while the path enters in front of the restored state: about (2048 + 64 + T/2) columns per strip
+// against (query length + 64 + T/2) for every strip in the unchained pass -- a third of the work at 8 000 events.
+template <bool STD>
+__global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArgs a) {
+    const int li = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (li >= a.n_long) return;  // wave-uniform
+    const int job = a.w_job[li];
+    if (job < 0) return;  // nothing aligned
+    const int lane = threadIdx.x & 63;
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[4 * kXchWordsPerWave];
+    Exchange xc;
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
+
+    const int read = a.reads[li];
+    const int64_t qo = a.q_off[read];
+    const int qlen = static_cast<int>(a.q_off[read + 1] - qo);
+    const float *q = a.queries + qo;
+    const int n_strips = (qlen + kStripRows - 1) / kStripRows;
+    const int rlen = a.job_len[job];
+    const float *yp = a.ref + a.job_off[job] - lane;
+    const int64_t per = a.bnd_off[a.n_jobs];
+    const float *rows = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];  // row s at rows + s * per
+    const int nck = (rlen - 1) >> a.ck_shift;
+    const int T = 1 << a.ck_shift;
+    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * ((kStripR + 1) * 64) + lane;
+
+    int e = min(a.w_ws[li], rlen - 1);  // column of the cell to reach: the winning cell, then the entry columns
+    float want = a.w_score[li];         // ... and its cost
+    int t_end = -1, t_st = -1;
+    StripResult res;
+    res.top.init();
+    for (int sidx = n_strips - 1; sidx >= 0; --sidx) {
+        const int row0 = sidx * kStripRows;
+        const int nrows = min(kStripRows, qlen - row0);
+        const int lq = (nrows - 1) / kStripR;
+        const int rq = (nrows - 1) - lq * kStripR;
+        float x[kStripR];
+#pragma unroll
+        for (int r = 0; r < kStripR; ++r) {
+            const int i = row0 + lane * kStripR + r;
+            const int src = a.rev_query ? (qlen - 1 - i) : i;
+            x[r] = (i < qlen) ? q[src] : 0.0f;
+        }
+        const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
+        float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
+        const int from = e - (a.trace_margin >= 0 ? a.trace_margin : nrows + 64);
+        int k = from > 0 ? min(from >> a.ck_shift, nck) : 0, back = 1, b = -1, hit = -1;
+        for (int attempt = 0; attempt < 40; ++attempt) {  // until the entry is known (k reaches 0 after <= 32 halvings)
+            res.cap_end = -1;
+            res.cap_st = -1;
+            if (sidx == 0)
+                strip_sweep<STD, true, true, true>(yp, rlen, e + 1, qlen, true, x, lq, rq, lane, xc, nullptr, nullptr, nullptr, nullptr, res, job, e,
+                                                   want, k * T, ckp, a.ck_shift, nck);
+            else
+                strip_sweep<STD, false, true, true>(yp, rlen, e + 1, qlen, true, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, e,
+                                                    want, k * T, ckp, a.ck_shift, nck);
+            b = __builtin_amdgcn_readlane(res.cap_st, lq);  // lq: wave-uniform
+            hit = __builtin_amdgcn_readlane(res.cap_end, lq);
+            if (b >= 0 || k == 0 || hit < 0) break;
+            k = max(0, k - back);  // the path enters before this checkpoint
+            back <<= 1;
+        }
+        if (sidx == n_strips - 1) t_end = hit;
+        if (hit < 0 || b < 0) {  // the cell was not met with its cost (never seen; reported as an unaligned read rather than a wrong one)
+            t_end = -1;
+            break;
+        }
+        if (sidx == 0) {
+            t_st = b;
+        } else {
+            e = b;
+            want = bin_c[b];
+        }
+    }
+    if (lane == 0) {
+        a.t_st[li] = t_st;
+        a.t_end[li] = t_end;
+    }
+}
+
 // instantiated in sdtw_inst_strips.hip
+extern template __global__ void sdtw_strip_chain_kernel<false>(const StripArgs);
+extern template __global__ void sdtw_strip_chain_kernel<true>(const StripArgs);
 extern template __global__ void sdtw_strip_pipe_kernel<false>(const StripArgs);
 extern template __global__ void sdtw_strip_pipe_kernel<true>(const StripArgs);
 extern template __global__ void sdtw_strip_kernel<false, false>(const StripArgs);

@@ -123,6 +123,8 @@ struct sfa_ctx {
     int device = 0;
     uint32_t flag = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_long = nullptr;       // the row strips of long queries run beside the wave kernels of the same batch
+    hipEvent_t lev[2] = {nullptr, nullptr};  // inputs of the batch ready on `stream` / strips done on `stream_long`
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end, row strips start
     hipEvent_t eev[4] = {nullptr, nullptr, nullptr, nullptr};  // sfa_align_raw: event detection start/end, normalisation start/end
     bool eev_pending = false;
@@ -141,6 +143,8 @@ struct sfa_ctx {
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
+    int64_t opt_long_overlap = 1;            // row strips on their own stream, beside the wave kernels of the batch (0: behind them)
+    int64_t opt_strip_chain = 1;             // row strips, pass 2: strip by strip from the last one upwards over short column ranges (1) or all strips over the whole range (0)
     int64_t opt_strip_pipeline = 1;          // row strips, pass 1: one wave per strip following the strip above (1) or one wave per (read, job) (0)
     int64_t opt_fused_trace = 1;             // 1: with LDS checkpoints, pass 2 rides in the fill launch as trailing tickets (fills the drain)
     int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
@@ -292,7 +296,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
 // overwrites the (invalid) rows they left for these reads.  Reads are taken in groups whose boundary rows fit the
 // checkpoint budget.
 int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const int64_t *q_off_host, const std::vector<int32_t> &reads, int64_t max_qlen,
-               ResultRow *d_out) {
+               ResultRow *d_out, hipStream_t st) {
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
     const size_t o_reads = 0, o_bnd = (sizeof(int32_t) * n_long + 7) & ~size_t(7);
     const size_t o_ck = o_bnd + sizeof(int64_t) * (n_jobs + 1);
@@ -334,7 +338,8 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
     // cost rows of every job: two in turn (classic pass 1, pass 2) or one per strip boundary (pipelined pass 1); start columns of
     // one job, two in turn (pass 2); + the checkpoints
     const bool pipe = c->opt_strip_pipeline != 0;
-    const int64_t cost_rows = pipe ? std::max<int64_t>(2, max_strips - 1) : 2;
+    const bool chain = c->opt_strip_chain != 0;  // pass 2 strip by strip from the last one upwards: needs every boundary row of pass 1
+    const int64_t cost_rows = (pipe || chain) ? std::max<int64_t>(2, max_strips - 1) : 2;
     const int64_t bytes_per_read = (per * cost_rows + row_max * 2) * 4 + ck_floats_per_read * 4;
     const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(n_long, c->opt_ckpt_budget / std::max<int64_t>(bytes_per_read, 1))));
     const size_t n_part = static_cast<size_t>(n_long) * n_jobs;
@@ -345,7 +350,6 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         (rc = c->d_lwin.reserve(4 * 5 * static_cast<size_t>(n_long))) ||
         (rc = c->d_lck.reserve(sizeof(float) * std::max<int64_t>(ck_floats_per_read, 1) * group)))
         return rc;
-    hipStream_t st = c->stream;
     if (c->d_bndc.cap != bndc_cap) HIP_TRY(hipMemsetAsync(c->d_bndc.p, 0x7f, c->d_bndc.cap, st));  // fresh allocation: 3.4e38 everywhere (see the pad note in sdtw_strips.hpp)
     HIP_TRY(hipMemcpyAsync(c->d_long.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
     const char *ds = c->d_long.as<char>();
@@ -365,6 +369,7 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.bnd_start = c->d_bnds.as<int32_t>();
         sa.bnd_row_max = row_max;
         sa.bnd_stride = cost_rows * per;
+        sa.keep_rows = chain ? 1 : 0;
         sa.p_best = c->d_lbest.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_second = c->d_lsecond.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_end = c->d_lend.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
@@ -428,7 +433,11 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         fa.mode = 1;
         hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, fgrid, fblock, 0, st, fa);
         KERNEL_TRY();
-        if (std_dtw)
+        if (chain && std_dtw)
+            hipLaunchKernelGGL((sfa::sdtw_strip_chain_kernel<true>), grid2, block, 0, st, sa);
+        else if (chain)
+            hipLaunchKernelGGL((sfa::sdtw_strip_chain_kernel<false>), grid2, block, 0, st, sa);
+        else if (std_dtw)
             hipLaunchKernelGGL((sfa::sdtw_strip_kernel<true, true>), grid2, block, 0, st, sa);
         else
             hipLaunchKernelGGL((sfa::sdtw_strip_kernel<false, true>), grid2, block, 0, st, sa);
@@ -640,6 +649,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     fz.t_st = c->d_tst.as<int32_t>();
     fz.out = d_out;
     fz.bad = c->d_bad.as<uint8_t>();
+    fz.q_off = da.q_off;
+    fz.max_query = long_reads.empty() ? 0 : sfa::kMaxQuery;
     fz.n_reads = n;
     fz.n_chunks = n_chunks;
     const dim3 fgrid((n + 255) / 256), fblock(256);
@@ -651,6 +662,22 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     hipLaunchKernelGGL(sfa::sdtw_screen_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_queries, da.q_off, n, c->d_bad.as<uint8_t>(),
                        c->d_badcount.as<unsigned>());
     KERNEL_TRY();
+    // Queries beyond 2048 events: row strips, on their own stream BESIDE the wave kernels of the shorter reads of the batch (a
+    // handful of short reads is one sweep's latency on an empty chip: 6 + 2.5 ms in front of 110 ms of strips when run in a
+    // row).  The two paths write disjoint rows (the finalize kernels here leave the long reads' rows alone).
+    int32_t long_launches = 0;
+    if (!long_reads.empty()) {
+        hipStream_t ls = st;
+        if (c->opt_long_overlap) {
+            ls = c->stream_long;
+            HIP_TRY(hipEventRecord(c->lev[0], st));  // queries, offsets and the non-finite screen are ready
+            HIP_TRY(hipStreamWaitEvent(ls, c->lev[0], 0));
+        }
+        c->prof.fill_launches = 0;  // (counted per group of long reads inside)
+        if ((rc = align_long(c, d_queries, da.q_off, q_off, long_reads, long_max, d_out, ls))) return rc;
+        long_launches = c->prof.fill_launches;
+        if (c->opt_long_overlap) HIP_TRY(hipEventRecord(c->lev[1], ls));
+    }
     if (n_quads > 0) {
         if (plan.lds_ckpt) {
             HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->d_gbest.p), 0x7f800000, static_cast<size_t>(n), st));  // +inf: no score seen yet
@@ -705,11 +732,11 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         HIP_TRY(hipEventRecord(c->ev[3], st));
     }
     }
-    c->prof.fill_launches = n_quads > 0 ? 1 : 0;
+    c->prof.fill_launches = (n_quads > 0 ? 1 : 0) + long_launches;
     c->long_pending = !long_reads.empty();
-    if (c->long_pending) {
+    if (c->long_pending) {  // join: what is left of the strips when the wave kernels are through counts as fill time
         HIP_TRY(hipEventRecord(c->ev[5], st));
-        if ((rc = align_long(c, d_queries, da.q_off, q_off, long_reads, long_max, d_out))) return rc;
+        if (c->opt_long_overlap) HIP_TRY(hipStreamWaitEvent(st, c->lev[1], 0));
     }
     HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[4], st));
@@ -874,6 +901,9 @@ static int create_context(sfa_ctx **out, const HostRef &h, uint32_t flag, int de
         return rc;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
+    for (auto &e : c->lev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     for (auto &e : c->eev)
@@ -994,6 +1024,9 @@ void sfa_destroy(sfa_ctx_t *c) {
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->eev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->lev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1037,6 +1070,10 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
         c->opt_widen_below = value;
     } else if (k == "strip_pipeline") {
         c->opt_strip_pipeline = value != 0;
+    } else if (k == "long_overlap") {
+        c->opt_long_overlap = value != 0;
+    } else if (k == "strip_chain") {
+        c->opt_strip_chain = value != 0;
     } else if (k == "fused_trace") {
         if (value < 0 || value > 2) return fail(SFA_EINVAL, "fused_trace must be 0 (off), 1 (launches with more tasks than wave slots) or 2 (always)");
         c->opt_fused_trace = value;

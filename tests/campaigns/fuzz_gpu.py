@@ -60,6 +60,8 @@ def main():
             opts["lds_ckpt"] = 0  # every snapshot to HBM (default: rolling in LDS where the shapes allow)
         if rng.integers(0, 3) == 0:
             opts["strip_pipeline"] = 0  # row strips: one wave per (read, job)
+        if rng.integers(0, 3) == 0:
+            opts["strip_chain"] = 0  # row strips, pass 2: all strips over the whole range
         opts["fused_trace"] = int(rng.choice([0, 1, 2, 2]))  # pass 2 as its own launch / by batch size / inside the fill launch
         if rng.integers(0, 4) == 0:
             opts["lds_ckpt"] = 2  # LDS checkpoints whatever the batch size

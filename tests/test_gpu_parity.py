@@ -38,6 +38,9 @@ MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "la
          "lds_fused": {"lds_ckpt": 2, "fused_trace": 2, "lane_widening": 1},
          "lds_unfused": {"lds_ckpt": 2, "fused_trace": 0, "lane_widening": 1},
          "classic_strips": {"strip_pipeline": 0},  # row strips: one wave per (read, job) instead of one per strip
+         "unchained_strips": {"strip_chain": 0},  # row strips, pass 2: all strips over the whole range instead of strip by strip from the last one upwards
+         "classic_unchained_strips": {"strip_pipeline": 0, "strip_chain": 0},  # (two boundary rows in turn, as in round 1)
+         "strips_backoff": {"trace_margin": 0, "ckpt_interval": 64},  # every strip of the chained pass 2 backs off
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
          "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
          "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}
@@ -146,7 +149,8 @@ def test_long_queries(oracle, seed, mode, gpu_mode):
     assert_rows_equal(got, want)
 
 
-@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto", "classic_strips"])
+@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto", "classic_strips", "unchained_strips", "classic_unchained_strips",
+                                      "strips_backoff"])
 @pytest.mark.parametrize("seed", range(4))
 @pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
 def test_row_strips(oracle, seed, mode, gpu_mode):
@@ -203,6 +207,16 @@ def test_row_strips_ncov_and_groups(oracle):
         assert al.profile()["fill_launches"] == 1 + 3
         al.set_option("strip_pipeline", 0)  # one wave per (read, job)
         assert al.align_db(q, q_off).tobytes() == got.tobytes()
+        al.set_option("strip_chain", 0)  # pass 2 over all strips at once
+        assert al.align_db(q, q_off).tobytes() == got.tobytes()
+        al.set_option("strip_pipeline", 1)
+        assert al.align_db(q, q_off).tobytes() == got.tobytes()
+        al.set_option("strip_chain", 1)
+        al.set_option("ckpt_budget_bytes", 16 << 30)
+        for interval, margin in ((64, 0), (4, 3), (4096, -1), (512, 100)):  # ... and the chained pass 2 with all reads in one launch
+            al.set_option("ckpt_interval", interval)
+            al.set_option("trace_margin", margin)
+            assert al.align_db(q, q_off).tobytes() == got.tobytes()
 
 
 def test_row_strips_extreme_lengths(oracle):
