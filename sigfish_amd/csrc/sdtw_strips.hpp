@@ -146,10 +146,10 @@ struct StripResult {
     int cap_end, cap_st;  // pass 2
 };
 
-// One strip over columns [0, ncols) of one (contig,strand).  `last`: the strip holds the last query row (lane lq,
+// One strip over columns [0, ncols) of one (contig,strand).  LAST: the strip holds the last query row (lane lq,
 // register rq).  Pass 2 (TRACK): [ws, ncols) is the winning window and `best` its minimum.
-template <bool STD, bool FIRST, bool TRACK, bool CHAIN = false>
-__device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen, const bool last,
+template <bool STD, bool FIRST, bool TRACK, bool CHAIN, bool LAST>
+__device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen,
                                             const float (&x)[kStripR], const int lq, const int rq, const int lane, Exchange &xc,
                                             const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
                                             const int job, const int ws, const float best, const int t_begin, float *ckp,
@@ -194,7 +194,7 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
 
     // lane lq meets column ncols - 1 at step ncols - 1 + lq; pass 1 stores a boundary row four columns at a time, the last
     // group is complete up to three steps later (columns past ncols - 1 land in the pad behind the row)
-    const int n_steps = ncols + lq + ((!TRACK && !last) ? 4 : 0);
+    const int n_steps = ncols + lq + ((!TRACK && !LAST) ? 4 : 0);
     typename Vec<float, 4>::type ob = {0.0f, 0.0f, 0.0f, 0.0f};
     // hand-over of the boundary row in blocks of kPipeBlock columns (a multiple of the 64-column chunk).  The consumer loads a
     // chunk one chunk ahead -- inside steps [t0, t0 + kPipeBlock) it touches the columns below t0 + kPipeBlock + 64 --, the
@@ -220,7 +220,11 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
         if (TRACK && !CHAIN) snxt = bin_s[t_begin + lane];
     }
     for (int t0 = t_begin; t0 < n_steps; t0 += 4) {
-        if (!TRACK) {
+        const int cpos = (t0 - t_begin) & 63;  // wave-uniform: position of step t0 inside the 64-column chunk
+        // everything that is not a step happens at a chunk start or (checkpoint intervals below 64) at a multiple of T: ONE test
+        // per block in the steady state
+        const bool housekeeping = cpos == 0 || (T < 64 && (t0 & (T - 1)) == 0);
+        if (!TRACK && __builtin_expect(housekeeping, 0)) {
             if (!FIRST && prog_in && t0 >= wait_next) wait_for_row(t0);
             if (prog_out && t0 >= pub_next) {  // the stores of the columns below t0 - 64 have reached memory, then the counter says so
                 publish_fence();
@@ -235,7 +239,6 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             }
         }
         const float4u ynext = *reinterpret_cast<const float4u *>(yp + t0 + 4);
-        const int cpos = (t0 - t_begin) & 63;  // wave-uniform: position of step t0 inside the chunk
         if (!FIRST && cpos == 0) {
             // Past column ncols - 1 (up to kBndPad words) this reads words nobody wrote for this read and job: left-overs
             // of an earlier sweep, or the fill pattern of the allocation.  They only ever reach cells of columns >= ncols,
@@ -260,38 +263,40 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                 if (TRACK) bsup = CHAIN ? t : __builtin_amdgcn_readlane(scur, cpos + u);
             }
             strip_step<STD, FIRST, TRACK>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc, bup, bsup);
-            if (!CHAIN && !last && !TRACK) {
-                // (wave-uniform) lane 63 is at column t - 63 of the strip's last row; t0 is a multiple of 4, so the column is
-                // u + 1 (mod 4): four columns are collected and stored as one aligned 16-byte word when the fourth arrives
+            // (everything below is branch-free but for the end of a window: a taken branch per step costs this loop a fifth of its
+            // time -- the wave kernels' sweep has none either)
+            if (!LAST && !TRACK) {
+                // lane 63 is at column t - 63 of the strip's last row; t0 is a multiple of 4, so the column is u + 1 (mod 4):
+                // four columns are collected and stored as one aligned 16-byte word when the fourth arrives
                 ob[(u + 1) & 3] = c[kStripR - 1];
                 if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob, prog_out != nullptr);
-            } else if (!CHAIN && !last) {
+            } else if (!LAST) {
                 const int col = t - 63;
                 if (lane == 63 && col >= 0 && col < ncols) {
                     bout_c[col] = c[kStripR - 1];
                     bout_s[col] = s[kStripR - 1];
                 }
             } else {
-                const int col = t - lq;  // wave-uniform
-                if (col >= 0 && col < ncols) {
-                    const float cl = c[rq];
-                    if (TRACK) {  // first cell of the winning window that attains the winning score
-                        const bool hit = res.cap_end < 0 && col >= ws && cl == best;
-                        res.cap_end = hit ? col : res.cap_end;
-                        res.cap_st = hit ? static_cast<int>(s[rq]) : res.cap_st;
-                    } else if (!STD) {
-                        const bool lt = cl < wmin;
-                        wmin = lt ? cl : wmin;
-                        wpos = lt ? col : wpos;
-                        if (col + 1 == wend) {
-                            res.top.offer(wmin, wpos, -1, job);
-                            wmin = INFINITY;
-                            wpos = -1;
-                            wend = min(wend + qlen, rlen);
-                        }
-                    } else if (col == rlen - 1) {
-                        res.top.offer(cl, col, -1, job);
+                const int col = t - lq;                        // wave-uniform
+                const bool inside = col >= 0 && col < ncols;   // wave-uniform
+                const float cl = c[rq];
+                if (TRACK) {  // first cell of the winning window that attains the winning score
+                    const bool hit = inside && res.cap_end < 0 && col >= ws && cl == best;
+                    res.cap_end = hit ? col : res.cap_end;
+                    res.cap_st = hit ? static_cast<int>(s[rq]) : res.cap_st;
+                } else if (!STD) {
+                    const float cv = inside ? cl : INFINITY;
+                    const bool lt = cv < wmin;
+                    wmin = lt ? cv : wmin;
+                    wpos = lt ? col : wpos;
+                    if (__builtin_expect(col + 1 == wend, 0)) {  // (wend <= ncols: never outside)
+                        res.top.offer(wmin, wpos, -1, job);
+                        wmin = INFINITY;
+                        wpos = -1;
+                        wend = min(wend + qlen, rlen);
                     }
+                } else if (__builtin_expect(col == rlen - 1, 0)) {
+                    res.top.offer(cl, col, -1, job);
                 }
             }
         }
@@ -375,12 +380,16 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
             int32_t *bout_s = TRACK ? bs + (sidx & 1) * a.bnd_row_max : nullptr;
             const int32_t *bin_s = TRACK ? bs + ((sidx & 1) ^ 1) * a.bnd_row_max : nullptr;
             float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
+            // (a strip is long enough for three copies of the loop to pay: first / in between / last)
             if (sidx == 0)
-                strip_sweep<STD, true, TRACK>(yp, rlen, ncols, qlen, last, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws, best,
-                                              k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, true, TRACK, false, false>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
+                                                            best, k * T, ckp, a.ck_shift, nck);
+            else if (!last)
+                strip_sweep<STD, false, TRACK, false, false>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
+                                                             best, k * T, ckp, a.ck_shift, nck);
             else
-                strip_sweep<STD, false, TRACK>(yp, rlen, ncols, qlen, last, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws, best,
-                                               k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, false, TRACK, false, true>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
+                                                            best, k * T, ckp, a.ck_shift, nck);
             // the boundary row was stored by lane 63 and is loaded by every lane of the same wave in the next strip: complete
             // the stores and drop the lines the vector cache may still hold from two strips ago
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -468,12 +477,15 @@ __global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs
     res.cap_st = -1;
     float *bout_c = last ? nullptr : rows + static_cast<int64_t>(sidx) * per;
     const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
-    if (sidx == 0)
-        strip_sweep<STD, true, false>(yp, rlen, rlen, qlen, last, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0, ckp,
-                                      a.ck_shift, nck, nullptr, last ? nullptr : prog + sidx);
+    if (sidx == 0)  // (queries of this path have more than one strip: the first is never the last)
+        strip_sweep<STD, true, false, false, false>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0,
+                                                    ckp, a.ck_shift, nck, nullptr, prog + sidx);
+    else if (!last)
+        strip_sweep<STD, false, false, false, false>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0,
+                                                     ckp, a.ck_shift, nck, prog + sidx - 1, prog + sidx);
     else
-        strip_sweep<STD, false, false>(yp, rlen, rlen, qlen, last, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0, ckp,
-                                       a.ck_shift, nck, prog + sidx - 1, last ? nullptr : prog + sidx);
+        strip_sweep<STD, false, false, false, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, 0, 0.0f, 0,
+                                                    ckp, a.ck_shift, nck, prog + sidx - 1, nullptr);
     if (last && lane == lq) {
         const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
         a.p_best[o] = res.top.best;
@@ -546,11 +558,11 @@ __global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArg
             res.cap_end = -1;
             res.cap_st = -1;
             if (sidx == 0)
-                strip_sweep<STD, true, true, true>(yp, rlen, e + 1, qlen, true, x, lq, rq, lane, xc, nullptr, nullptr, nullptr, nullptr, res, job, e,
-                                                   want, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, true, true, true, true>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, nullptr, nullptr, nullptr, nullptr, res, job, e,
+                                                         want, k * T, ckp, a.ck_shift, nck);
             else
-                strip_sweep<STD, false, true, true>(yp, rlen, e + 1, qlen, true, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, e,
-                                                    want, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, false, true, true, true>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, e,
+                                                          want, k * T, ckp, a.ck_shift, nck);
             b = __builtin_amdgcn_readlane(res.cap_st, lq);  // lq: wave-uniform
             hit = __builtin_amdgcn_readlane(res.cap_end, lq);
             if (b >= 0 || k == 0 || hit < 0) break;

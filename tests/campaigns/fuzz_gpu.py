@@ -62,6 +62,8 @@ def main():
             opts["strip_pipeline"] = 0  # row strips: one wave per (read, job)
         if rng.integers(0, 3) == 0:
             opts["strip_chain"] = 0  # row strips, pass 2: all strips over the whole range
+        if rng.integers(0, 4) == 0:
+            opts["long_overlap"] = 0  # row strips behind the wave kernels instead of beside them
         opts["fused_trace"] = int(rng.choice([0, 1, 2, 2]))  # pass 2 as its own launch / by batch size / inside the fill launch
         if rng.integers(0, 4) == 0:
             opts["lds_ckpt"] = 2  # LDS checkpoints whatever the batch size
