@@ -31,8 +31,22 @@
 
 namespace sfa {
 
-constexpr int kStripR = 32;                 // query rows per lane
-constexpr int kStripRows = 64 * kStripR;    // query rows per strip
+constexpr int kStripR = 32;                 // query rows per lane, at most
+constexpr int kStripRows = 64 * kStripR;    // query rows per strip, at most: a query has ceil(qlen / 2048) strips
+constexpr int kCkRec = (kStripR + 1) * 64;  // floats per checkpoint record: a plane of 64 lanes per row of a lane (up to 32) ...
+constexpr int kCkDprev = kStripR * 64;      // ... and the plane of the diagonal inputs
+
+// BALANCED STRIPS.  The strips of a query all have the same height, 64 lanes x R rows with the smallest R of {20, 24, 28, 32}
+// that covers the query: 3 000 events are 2 strips of 64 x 24 rows (1 536 + 1 464) instead of 2 048 + 952 rows at R = 32 -- the
+// sweep of a strip costs its R, whatever the number of lanes that hold rows, so a quarter of the time goes with the quarter of
+// padding.  (At least 80 % of the rows of the strips of any query are query rows.)  R is a function of the query length alone:
+// both passes, the boundary rows and the checkpoints of a read use the same one.
+__host__ __device__ inline int strip_rows_per_lane(const int qlen, const int balanced) {
+    const int n_strips = (qlen + kStripRows - 1) / kStripRows;
+    const int per_lane = (qlen + 64 * n_strips - 1) / (64 * n_strips);
+    const int R = !balanced ? kStripR : (per_lane <= 20 ? 20 : (per_lane <= 24 ? 24 : (per_lane <= 28 ? 28 : 32)));
+    return 64 * R * (n_strips - 1) < qlen ? R : kStripR;  // (always: the last strip holds at least one row)
+}
 constexpr int kBndPad = 256;                // words behind every boundary row (block over-run of the sweep + prefetch)
 
 struct StripArgs {
@@ -63,6 +77,7 @@ struct StripArgs {
     const int32_t *strip_off;   // [n_long+1] prefix sum of the reads' strip counts
     int32_t *progress;          // [n_long][n_jobs][max_strips] columns of the strip's last row that are complete and visible
     unsigned *ticket;           // task counter (zeroed before the launch)
+    int32_t balanced;           // 1: rows per lane by query length (strip_rows_per_lane), 0: always 32
     int32_t keep_rows;          // classic pass 1: 1 = strip s writes boundary row s (bnd_stride rows per read) instead of two rows in turn
 };
 
@@ -71,16 +86,16 @@ struct StripArgs {
 #endif
 constexpr int kPipeBlock = SFA_PIPE_BLOCK;  // columns between two hand-overs of a boundary row (one release / acquire pair each)
 
-// One anti-diagonal step of a strip: dp_step<32, TRACK> with the handling of query row 0 made conditional on FIRST (the
+// One anti-diagonal step of a strip: dp_step<R, TRACK> with the handling of query row 0 made conditional on FIRST (the
 // strip that contains it).
-template <bool STD, bool FIRST, bool TRACK>
-__device__ __forceinline__ void strip_step(typename Vec<float, kStripR>::type &c, typename Vec<int, kStripR>::type &s, float &dprev,
-                                           int &sdprev, const float (&x)[kStripR], const float yv, const int t, const bool lane0,
+template <bool STD, bool FIRST, bool TRACK, int R>
+__device__ __forceinline__ void strip_step(typename Vec<float, R>::type &c, typename Vec<int, R>::type &s, float &dprev,
+                                           int &sdprev, const float (&x)[R], const float yv, const int t, const bool lane0,
                                            Exchange &xc, const float bup = 0.0f, const int bsup = 0) {
     // bup / bsup (wave-uniform; strips below the first): the cell above lane 0's first row, from the boundary row in HBM
-    float up = xc.shift(static_cast<float>(c[kStripR - 1]));
+    float up = xc.shift(static_cast<float>(c[R - 1]));
     int sup = 0;
-    if (TRACK) sup = xc.shift(static_cast<int>(s[kStripR - 1]));
+    if (TRACK) sup = xc.shift(static_cast<int>(s[R - 1]));
     if (!FIRST) {
         up = lane0 ? bup : up;
         if (TRACK) sup = lane0 ? bsup : sup;
@@ -94,7 +109,7 @@ __device__ __forceinline__ void strip_step(typename Vec<float, kStripR>::type &c
     sdprev = sup;
     if (STD && FIRST) dprev = (t == 0) ? INFINITY : dprev;  // there is no column -1 next to the free corner
 #pragma unroll
-    for (int r = 0; r < kStripR; ++r) {
+    for (int r = 0; r < R; ++r) {
         const float left = c[r];
         const int sleft = s[r];
         float m;
@@ -148,9 +163,9 @@ struct StripResult {
 
 // One strip over columns [0, ncols) of one (contig,strand).  LAST: the strip holds the last query row (lane lq,
 // register rq).  Pass 2 (TRACK): [ws, ncols) is the winning window and `best` its minimum.
-template <bool STD, bool FIRST, bool TRACK, bool CHAIN, bool LAST>
+template <bool STD, bool FIRST, bool TRACK, bool CHAIN, bool LAST, int R>
 __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen,
-                                            const float (&x)[kStripR], const int lq, const int rq, const int lane, Exchange &xc,
+                                            const float (&x)[R], const int lq, const int rq, const int lane, Exchange &xc,
                                             const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
                                             const int job, const int ws, const float best, const int t_begin, float *ckp,
                                             const int ck_shift, const int nck, const int32_t *prog_in = nullptr, int32_t *prog_out = nullptr) {
@@ -158,22 +173,22 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     // far this sweep has got with the row it writes.  Both wave-uniform; nullptr: the rows are complete / nobody is waiting.
     // ckp: this strip's checkpoint records (+ lane).  Pass 1 stores record k - 1 before step k*T; pass 2 resumes from the
     // record of step t_begin (t_begin = 0: from the initial state).
-    typename Vec<float, kStripR>::type c;
-    typename Vec<int, kStripR>::type s;
+    typename Vec<float, R>::type c;
+    typename Vec<int, R>::type s;
     float dprev = INFINITY;
     int sdprev = 0;
     if (TRACK && t_begin > 0) {  // exact costs; where these cells came from is unknown (-1)
-        const float *rec = ckp + static_cast<int64_t>((t_begin >> ck_shift) - 1) * ((kStripR + 1) * 64);
+        const float *rec = ckp + static_cast<int64_t>((t_begin >> ck_shift) - 1) * kCkRec;
 #pragma unroll
-        for (int r = 0; r < kStripR; ++r) {
+        for (int r = 0; r < R; ++r) {
             c[r] = rec[r * 64];
             s[r] = -1;
         }
-        dprev = rec[kStripR * 64];
+        dprev = rec[kCkDprev];
         sdprev = (CHAIN && !FIRST && lane == 0) ? t_begin - 1 : -1;  // lane 0's diagonal input is the row above, column t_begin - 1
     } else {
 #pragma unroll
-        for (int r = 0; r < kStripR; ++r) {
+        for (int r = 0; r < R; ++r) {
             c[r] = INFINITY;
             s[r] = 0;
         }
@@ -232,10 +247,10 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                 pub_next = t0 + kPipeBlock;
             }
             if (t0 > 0 && (t0 & (T - 1)) == 0 && t0 <= ck_last) {  // wave-uniform: snapshot of the state before step t0
-                float *rec = ckp + static_cast<int64_t>((t0 >> ck_shift) - 1) * ((kStripR + 1) * 64);
+                float *rec = ckp + static_cast<int64_t>((t0 >> ck_shift) - 1) * kCkRec;
 #pragma unroll
-                for (int r = 0; r < kStripR; ++r) rec[r * 64] = c[r];
-                rec[kStripR * 64] = dprev;
+                for (int r = 0; r < R; ++r) rec[r * 64] = c[r];
+                rec[kCkDprev] = dprev;
             }
         }
         const float4u ynext = *reinterpret_cast<const float4u *>(yp + t0 + 4);
@@ -262,19 +277,19 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                 // CHAIN: what is carried is the COLUMN of the row above through which the path enters this strip
                 if (TRACK) bsup = CHAIN ? t : __builtin_amdgcn_readlane(scur, cpos + u);
             }
-            strip_step<STD, FIRST, TRACK>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc, bup, bsup);
+            strip_step<STD, FIRST, TRACK, R>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc, bup, bsup);
             // (everything below is branch-free but for the end of a window: a taken branch per step costs this loop a fifth of its
             // time -- the wave kernels' sweep has none either)
             if (!LAST && !TRACK) {
                 // lane 63 is at column t - 63 of the strip's last row; t0 is a multiple of 4, so the column is u + 1 (mod 4):
                 // four columns are collected and stored as one aligned 16-byte word when the fourth arrives
-                ob[(u + 1) & 3] = c[kStripR - 1];
+                ob[(u + 1) & 3] = c[R - 1];
                 if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob, prog_out != nullptr);
             } else if (!LAST) {
                 const int col = t - 63;
                 if (lane == 63 && col >= 0 && col < ncols) {
-                    bout_c[col] = c[kStripR - 1];
-                    bout_s[col] = s[kStripR - 1];
+                    bout_c[col] = c[R - 1];
+                    bout_s[col] = s[R - 1];
                 }
             } else {
                 const int col = t - lq;                        // wave-uniform
@@ -308,32 +323,44 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     }
 }
 
-// Pass 1 (TRACK = false): wave-task = (long read, job).  Pass 2 (TRACK = true): wave-task = long read, its winning job.
-// 4 waves per block.
-template <bool STD, bool TRACK>
-__global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const StripArgs a) {
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (task >= (TRACK ? a.n_long : a.n_long * a.n_jobs)) return;  // wave-uniform
-    int job, li;
-    if (TRACK) {
-        li = task;
-        job = a.w_job[li];
-        if (job < 0) return;  // nothing aligned (no candidate at all)
-    } else {
-        job = task / a.n_long;  // job-major: neighbouring waves stream the same reference
-        li = task - job * a.n_long;
-    }
-    const int lane = threadIdx.x & 63;
-    __shared__ float lds_f[4 * kXchWordsPerWave];
-    __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
-    Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
-
+// What every strip kernel knows about its read.
+struct StripRead {
+    const float *q;  // the query
+    int qlen, n_strips;
+};
+__device__ __forceinline__ StripRead strip_read(const StripArgs &a, const int li) {
     const int read = a.reads[li];
     const int64_t qo = a.q_off[read];
-    const int qlen = static_cast<int>(a.q_off[read + 1] - qo);
-    const float *q = a.queries + qo;
-    const int n_strips = (qlen + kStripRows - 1) / kStripRows;
+    StripRead r;
+    r.qlen = static_cast<int>(a.q_off[read + 1] - qo);
+    r.q = a.queries + qo;
+    r.n_strips = (r.qlen + kStripRows - 1) / kStripRows;
+    return r;
+}
+// the R query rows of this lane in strip `sidx` (64 R rows per strip); rows past the query are zeros
+template <int R>
+__device__ __forceinline__ void strip_rows(const StripArgs &a, const StripRead &rd, const int sidx, const int lane, float (&x)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = sidx * 64 * R + lane * R + r;
+        const int src = a.rev_query ? (rd.qlen - 1 - i) : i;
+        x[r] = (i < rd.qlen) ? rd.q[src] : 0.0f;
+    }
+}
+// the kernels pick the body for the read's rows per lane (wave-uniform)
+#define SFA_STRIP_DISPATCH(BODY, qlen, ...)                    \
+    switch (strip_rows_per_lane(qlen, a.balanced)) {          \
+        case 20: BODY<STD, 20>(__VA_ARGS__); break;           \
+        case 24: BODY<STD, 24>(__VA_ARGS__); break;           \
+        case 28: BODY<STD, 28>(__VA_ARGS__); break;           \
+        default: BODY<STD, 32>(__VA_ARGS__); break;           \
+    }
+
+// Pass 1 (TRACK = false): wave-task = (long read, job).  Pass 2 (TRACK = true): wave-task = long read, its winning job.
+// 4 waves per block.
+template <bool STD, bool TRACK, int R>
+__device__ __forceinline__ void strip_task(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
+    const int qlen = rd.qlen, n_strips = rd.n_strips;
     const int rlen = a.job_len[job];
     const float *yp = a.ref + a.job_off[job] - lane;  // this lane's column at step t is t - lane
     const int64_t per = a.bnd_off[a.n_jobs];
@@ -354,7 +381,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
         const int from = ws - (a.trace_margin >= 0 ? a.trace_margin : qlen + 64);
         k = from > 0 ? min(from >> a.ck_shift, nck) : 0;
     }
-    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * ((kStripR + 1) * 64) + lane;
+    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * kCkRec + lane;
     StripResult res;
     res.top.init();
     int lq = 0;
@@ -362,34 +389,28 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
         res.cap_end = -1;
         res.cap_st = -1;
         for (int sidx = 0; sidx < n_strips; ++sidx) {
-            const int row0 = sidx * kStripRows;
-            const int rows = min(kStripRows, qlen - row0);
+            const int rows = min(64 * R, qlen - sidx * 64 * R);
             const bool last = sidx == n_strips - 1;
-            lq = (rows - 1) / kStripR;
-            const int rq = (rows - 1) - lq * kStripR;
-            float x[kStripR];
-#pragma unroll
-            for (int r = 0; r < kStripR; ++r) {
-                const int i = row0 + lane * kStripR + r;
-                const int src = a.rev_query ? (qlen - 1 - i) : i;
-                x[r] = (i < qlen) ? q[src] : 0.0f;
-            }
+            lq = (rows - 1) / R;
+            const int rq = (rows - 1) - lq * R;
+            float x[R];
+            strip_rows<R>(a, rd, sidx, lane, x);
             // two rows in turn, or (pass 1 with the chained pass 2 behind it) one row per strip boundary, kept
             float *bout_c = bc + ((!TRACK && a.keep_rows) ? sidx : (sidx & 1)) * per;
             const float *bin_c = bc + ((!TRACK && a.keep_rows) ? sidx - 1 : ((sidx & 1) ^ 1)) * per;
             int32_t *bout_s = TRACK ? bs + (sidx & 1) * a.bnd_row_max : nullptr;
             const int32_t *bin_s = TRACK ? bs + ((sidx & 1) ^ 1) * a.bnd_row_max : nullptr;
-            float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
+            float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * kCkRec;
             // (a strip is long enough for three copies of the loop to pay: first / in between / last)
             if (sidx == 0)
-                strip_sweep<STD, true, TRACK, false, false>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
-                                                            best, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, true, TRACK, false, false, R>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
+                                                               best, k * T, ckp, a.ck_shift, nck);
             else if (!last)
-                strip_sweep<STD, false, TRACK, false, false>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
-                                                             best, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, false, TRACK, false, false, R>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
+                                                                best, k * T, ckp, a.ck_shift, nck);
             else
-                strip_sweep<STD, false, TRACK, false, true>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
-                                                            best, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, false, TRACK, false, true, R>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
+                                                               best, k * T, ckp, a.ck_shift, nck);
             // the boundary row was stored by lane 63 and is loaded by every lane of the same wave in the next strip: complete
             // the stores and drop the lines the vector cache may still hold from two strips ago
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -413,6 +434,40 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
         }
     }
 }
+template <bool STD, int R>
+__device__ __forceinline__ void strip_task_fill(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
+    strip_task<STD, false, R>(a, rd, li, job, lane, xc);
+}
+template <bool STD, int R>
+__device__ __forceinline__ void strip_task_trace(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
+    strip_task<STD, true, R>(a, rd, li, job, lane, xc);
+}
+
+template <bool STD, bool TRACK>
+__global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const StripArgs a) {
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (task >= (TRACK ? a.n_long : a.n_long * a.n_jobs)) return;  // wave-uniform
+    int job, li;
+    if (TRACK) {
+        li = task;
+        job = a.w_job[li];
+        if (job < 0) return;  // nothing aligned (no candidate at all)
+    } else {
+        job = task / a.n_long;  // job-major: neighbouring waves stream the same reference
+        li = task - job * a.n_long;
+    }
+    const int lane = threadIdx.x & 63;
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
+    Exchange xc;
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
+    const StripRead rd = strip_read(a, li);
+    if (TRACK) {
+        SFA_STRIP_DISPATCH(strip_task_trace, rd.qlen, a, rd, li, job, lane, xc)
+    } else {
+        SFA_STRIP_DISPATCH(strip_task_fill, rd.qlen, a, rd, li, job, lane, xc)
+    }
+}
 
 // Pass 1, pipelined: wave-task = (job, long read, STRIP).  The classic pass 1 above gives one wave all the strips of a (read,
 // job), one after the other: few, long tasks -- 6 250 of them for 3 125 reads of 8 000 events, two-and-a-bit rounds of the
@@ -422,6 +477,46 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const St
 // strip: a strip's predecessor always holds a lower ticket, i.e. is running or done whenever the strip waits for it -- no
 // deadlock whatever order the hardware starts blocks in.  Everything else (checkpoints per strip, window scan in the final
 // strip, partial top-2 per (read, job)) is the classic pass 1's.
+template <bool STD, int R>
+__device__ __forceinline__ void strip_pipe_task(const StripArgs &a, const StripRead &rd, const int li, const int job, const int sidx, const int lane,
+                                                Exchange &xc) {
+    const int qlen = rd.qlen;
+    const int rlen = a.job_len[job];
+    const float *yp = a.ref + a.job_off[job] - lane;
+    const int64_t per = a.bnd_off[a.n_jobs];
+    float *rows = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];  // row s at rows + s * per
+    int32_t *prog = a.progress + (static_cast<int64_t>(li) * a.n_jobs + job) * a.max_strips;
+    const int nck = (rlen - 1) >> a.ck_shift;
+    float *ckp = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * kCkRec + lane + static_cast<int64_t>(sidx) * nck * kCkRec;
+    const int nrows = min(64 * R, qlen - sidx * 64 * R);
+    const bool last = sidx == rd.n_strips - 1;
+    const int lq = (nrows - 1) / R;
+    const int rq = (nrows - 1) - lq * R;
+    float x[R];
+    strip_rows<R>(a, rd, sidx, lane, x);
+    StripResult res;
+    res.top.init();
+    res.cap_end = -1;
+    res.cap_st = -1;
+    float *bout_c = last ? nullptr : rows + static_cast<int64_t>(sidx) * per;
+    const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
+    if (sidx == 0)  // (queries of this path have more than one strip: the first is never the last)
+        strip_sweep<STD, true, false, false, false, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0,
+                                                       ckp, a.ck_shift, nck, nullptr, prog + sidx);
+    else if (!last)
+        strip_sweep<STD, false, false, false, false, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f,
+                                                        0, ckp, a.ck_shift, nck, prog + sidx - 1, prog + sidx);
+    else
+        strip_sweep<STD, false, false, false, true, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, 0, 0.0f,
+                                                       0, ckp, a.ck_shift, nck, prog + sidx - 1, nullptr);
+    if (last && lane == lq) {
+        const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
+        a.p_best[o] = res.top.best;
+        a.p_second[o] = res.top.second;
+        a.p_end[o] = res.top.end;
+    }
+}
+
 template <bool STD>
 __global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs a) {
     const int lane = threadIdx.x & 63;
@@ -445,55 +540,9 @@ __global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs
     __shared__ int lds_i[1];
     Exchange xc;
     xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
-
-    const int read = a.reads[li];
-    const int64_t qo = a.q_off[read];
-    const int qlen = static_cast<int>(a.q_off[read + 1] - qo);
-    const float *q = a.queries + qo;
-    const int n_strips = (qlen + kStripRows - 1) / kStripRows;
-    const int rlen = a.job_len[job];
-    const float *yp = a.ref + a.job_off[job] - lane;
-    const int64_t per = a.bnd_off[a.n_jobs];
-    float *rows = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];  // row s at rows + s * per
-    int32_t *prog = a.progress + (static_cast<int64_t>(li) * a.n_jobs + job) * a.max_strips;
-    const int nck = (rlen - 1) >> a.ck_shift;
-    float *ckp = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * ((kStripR + 1) * 64) + lane +
-                 static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
-    const int row0 = sidx * kStripRows;
-    const int nrows = min(kStripRows, qlen - row0);
-    const bool last = sidx == n_strips - 1;
-    const int lq = (nrows - 1) / kStripR;
-    const int rq = (nrows - 1) - lq * kStripR;
-    float x[kStripR];
-#pragma unroll
-    for (int rr = 0; rr < kStripR; ++rr) {
-        const int i = row0 + lane * kStripR + rr;
-        const int src = a.rev_query ? (qlen - 1 - i) : i;
-        x[rr] = (i < qlen) ? q[src] : 0.0f;
-    }
-    StripResult res;
-    res.top.init();
-    res.cap_end = -1;
-    res.cap_st = -1;
-    float *bout_c = last ? nullptr : rows + static_cast<int64_t>(sidx) * per;
-    const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
-    if (sidx == 0)  // (queries of this path have more than one strip: the first is never the last)
-        strip_sweep<STD, true, false, false, false>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0,
-                                                    ckp, a.ck_shift, nck, nullptr, prog + sidx);
-    else if (!last)
-        strip_sweep<STD, false, false, false, false>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0,
-                                                     ckp, a.ck_shift, nck, prog + sidx - 1, prog + sidx);
-    else
-        strip_sweep<STD, false, false, false, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, 0, 0.0f, 0,
-                                                    ckp, a.ck_shift, nck, prog + sidx - 1, nullptr);
-    if (last && lane == lq) {
-        const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
-        a.p_best[o] = res.top.best;
-        a.p_second[o] = res.top.second;
-        a.p_end[o] = res.top.end;
-    }
+    const StripRead rd = strip_read(a, li);
+    SFA_STRIP_DISPATCH(strip_pipe_task, rd.qlen, a, rd, li, job, sidx, lane, xc)
 }
-
 
 // Pass 2, CHAINED (one wave per long read, its winning job): the strips are traced from the LAST one upwards, each over its own
 // short range of columns.  Pass 1 kept the last row of every strip (one row per strip boundary), so a strip can be swept on
@@ -508,30 +557,16 @@ __global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs
 // A strip of r rows is swept from the checkpoint r + 64 columns (or `trace_margin`) in front of its target cell and backs off
 // 1, 2, 4 ... checkpoints while the path enters in front of the restored state: about (2048 + 64 + T/2) columns per strip
 // against (query length + 64 + T/2) for every strip in the unchained pass -- a third of the work at 8 000 events.
-template <bool STD>
-__global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArgs a) {
-    const int li = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (li >= a.n_long) return;  // wave-uniform
-    const int job = a.w_job[li];
-    if (job < 0) return;  // nothing aligned
-    const int lane = threadIdx.x & 63;
-    __shared__ float lds_f[4 * kXchWordsPerWave];
-    __shared__ int lds_i[4 * kXchWordsPerWave];
-    Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
-
-    const int read = a.reads[li];
-    const int64_t qo = a.q_off[read];
-    const int qlen = static_cast<int>(a.q_off[read + 1] - qo);
-    const float *q = a.queries + qo;
-    const int n_strips = (qlen + kStripRows - 1) / kStripRows;
+template <bool STD, int R>
+__device__ __forceinline__ void strip_chain_task(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
+    const int qlen = rd.qlen, n_strips = rd.n_strips;
     const int rlen = a.job_len[job];
     const float *yp = a.ref + a.job_off[job] - lane;
     const int64_t per = a.bnd_off[a.n_jobs];
     const float *rows = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];  // row s at rows + s * per
     const int nck = (rlen - 1) >> a.ck_shift;
     const int T = 1 << a.ck_shift;
-    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * ((kStripR + 1) * 64) + lane;
+    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * kCkRec + lane;
 
     int e = min(a.w_ws[li], rlen - 1);  // column of the cell to reach: the winning cell, then the entry columns
     float want = a.w_score[li];         // ... and its cost
@@ -539,30 +574,24 @@ __global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArg
     StripResult res;
     res.top.init();
     for (int sidx = n_strips - 1; sidx >= 0; --sidx) {
-        const int row0 = sidx * kStripRows;
-        const int nrows = min(kStripRows, qlen - row0);
-        const int lq = (nrows - 1) / kStripR;
-        const int rq = (nrows - 1) - lq * kStripR;
-        float x[kStripR];
-#pragma unroll
-        for (int r = 0; r < kStripR; ++r) {
-            const int i = row0 + lane * kStripR + r;
-            const int src = a.rev_query ? (qlen - 1 - i) : i;
-            x[r] = (i < qlen) ? q[src] : 0.0f;
-        }
+        const int nrows = min(64 * R, qlen - sidx * 64 * R);
+        const int lq = (nrows - 1) / R;
+        const int rq = (nrows - 1) - lq * R;
+        float x[R];
+        strip_rows<R>(a, rd, sidx, lane, x);
         const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
-        float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * ((kStripR + 1) * 64);
+        float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * kCkRec;
         const int from = e - (a.trace_margin >= 0 ? a.trace_margin : nrows + 64);
         int k = from > 0 ? min(from >> a.ck_shift, nck) : 0, back = 1, b = -1, hit = -1;
         for (int attempt = 0; attempt < 40; ++attempt) {  // until the entry is known (k reaches 0 after <= 32 halvings)
             res.cap_end = -1;
             res.cap_st = -1;
             if (sidx == 0)
-                strip_sweep<STD, true, true, true, true>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, nullptr, nullptr, nullptr, nullptr, res, job, e,
-                                                         want, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, true, true, true, true, R>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, nullptr, nullptr, nullptr, nullptr, res, job, e,
+                                                            want, k * T, ckp, a.ck_shift, nck);
             else
-                strip_sweep<STD, false, true, true, true>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, e,
-                                                          want, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, false, true, true, true, R>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, e,
+                                                             want, k * T, ckp, a.ck_shift, nck);
             b = __builtin_amdgcn_readlane(res.cap_st, lq);  // lq: wave-uniform
             hit = __builtin_amdgcn_readlane(res.cap_end, lq);
             if (b >= 0 || k == 0 || hit < 0) break;
@@ -585,6 +614,21 @@ __global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArg
         a.t_st[li] = t_st;
         a.t_end[li] = t_end;
     }
+}
+
+template <bool STD>
+__global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArgs a) {
+    const int li = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (li >= a.n_long) return;  // wave-uniform
+    const int job = a.w_job[li];
+    if (job < 0) return;  // nothing aligned
+    const int lane = threadIdx.x & 63;
+    __shared__ float lds_f[4 * kXchWordsPerWave];
+    __shared__ int lds_i[4 * kXchWordsPerWave];
+    Exchange xc;
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
+    const StripRead rd = strip_read(a, li);
+    SFA_STRIP_DISPATCH(strip_chain_task, rd.qlen, a, rd, li, job, lane, xc)
 }
 
 // instantiated in sdtw_inst_strips.hip

@@ -143,6 +143,7 @@ struct sfa_ctx {
     int64_t opt_widen_below = 5;             // auto: widen (x4) when the batch has fewer waves per SIMD than this
     int64_t opt_trace_margin = -1;           // steps of head start for pass 2; -1 = qlen_max + 16
     int64_t opt_waves_per_simd = 6;          // target occupancy used when chunking the job list
+    int64_t opt_balanced_strips = 1;         // row strips of equal height, 64 x {20, 24, 28, 32} rows by query length (0: 64 x 32 and a short last one)
     int64_t opt_long_overlap = 1;            // row strips on their own stream, beside the wave kernels of the batch (0: behind them)
     int64_t opt_strip_chain = 1;             // row strips, pass 2: strip by strip from the last one upwards over short column ranges (1) or all strips over the whole range (0)
     int64_t opt_strip_pipeline = 1;          // row strips, pass 1: one wave per strip following the strip above (1) or one wave per (read, job) (0)
@@ -370,6 +371,7 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.bnd_row_max = row_max;
         sa.bnd_stride = cost_rows * per;
         sa.keep_rows = chain ? 1 : 0;
+        sa.balanced = c->opt_balanced_strips ? 1 : 0;
         sa.p_best = c->d_lbest.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_second = c->d_lsecond.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_end = c->d_lend.as<int32_t>() + static_cast<size_t>(g0) * n_jobs;
@@ -1070,6 +1072,8 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
         c->opt_widen_below = value;
     } else if (k == "strip_pipeline") {
         c->opt_strip_pipeline = value != 0;
+    } else if (k == "balanced_strips") {
+        c->opt_balanced_strips = value != 0;
     } else if (k == "long_overlap") {
         c->opt_long_overlap = value != 0;
     } else if (k == "strip_chain") {

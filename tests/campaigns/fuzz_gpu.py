@@ -63,6 +63,8 @@ def main():
         if rng.integers(0, 3) == 0:
             opts["strip_chain"] = 0  # row strips, pass 2: all strips over the whole range
         if rng.integers(0, 4) == 0:
+            opts["balanced_strips"] = 0  # row strips of 64 x 32 rows and a short last one
+        if rng.integers(0, 4) == 0:
             opts["long_overlap"] = 0  # row strips behind the wave kernels instead of beside them
         opts["fused_trace"] = int(rng.choice([0, 1, 2, 2]))  # pass 2 as its own launch / by batch size / inside the fill launch
         if rng.integers(0, 4) == 0:

@@ -41,6 +41,8 @@ MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "la
          "unchained_strips": {"strip_chain": 0},  # row strips, pass 2: all strips over the whole range instead of strip by strip from the last one upwards
          "classic_unchained_strips": {"strip_pipeline": 0, "strip_chain": 0},  # (two boundary rows in turn, as in round 1)
          "strips_backoff": {"trace_margin": 0, "ckpt_interval": 64},  # every strip of the chained pass 2 backs off
+         "tall_strips": {"balanced_strips": 0},  # strips of 64 x 32 rows and a short last one instead of equal heights
+         "tall_classic_strips": {"balanced_strips": 0, "strip_pipeline": 0, "strip_chain": 0},
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
          "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
          "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}
@@ -150,7 +152,7 @@ def test_long_queries(oracle, seed, mode, gpu_mode):
 
 
 @pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto", "classic_strips", "unchained_strips", "classic_unchained_strips",
-                                      "strips_backoff"])
+                                      "strips_backoff", "tall_strips", "tall_classic_strips"])
 @pytest.mark.parametrize("seed", range(4))
 @pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
 def test_row_strips(oracle, seed, mode, gpu_mode):
@@ -163,7 +165,9 @@ def test_row_strips(oracle, seed, mode, gpu_mode):
     quant = seed == 1
     lens = [int(x) for x in rng.integers(600, 7000, size=int(rng.integers(1, 4)))] + [int(rng.integers(3, 60)), int(rng.integers(60, 500))]
     ref = _small_ref(rng, lens, rna, quant)
-    qlens = rng.choice([0, 64, 250, 1000, 2048, 2049, 2100, 3000, 4095, 4096, 4097, 5000, 6500], size=int(rng.integers(3, 12)))
+    # (2560 / 3072 / 3584 / 5376: the last lengths of two / three strips of 64 x 20 / 24 / 28 rows)
+    qlens = rng.choice([0, 64, 250, 1000, 2048, 2049, 2100, 2560, 2561, 3000, 3072, 3073, 3584, 3585, 4095, 4096, 4097, 5000, 5376, 5377, 6500],
+                       size=int(rng.integers(3, 12)))
     qlens[0] = [2049, 4096, 4097, 6500][seed]
     if seed == 3:
         qlens = qlens[qlens > 2048]  # a batch of long reads only

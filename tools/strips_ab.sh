@@ -10,6 +10,10 @@ for o in "1 1" "1 0" "0 1" "0 0"; do
     run --workload $w --opt strip_pipeline=$1 --opt strip_chain=$2
   done
 done
+echo "== balanced_strips 0 (64 x 32 rows per strip and a short last one)"
+for w in ${WL:-ncov_r9_dna_q3000 ncov_r9_dna_q4000 ncov_r9_dna_q8000}; do
+  run --workload $w --opt balanced_strips=0
+done
 for n in ${LIBS}; do
   echo "== libsfa_$n.so (defaults)"
   for w in ${WL:-ncov_r9_dna_q3000 ncov_r9_dna_q4000 ncov_r9_dna_q8000}; do
