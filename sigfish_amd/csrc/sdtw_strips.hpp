@@ -571,6 +571,7 @@ __device__ __forceinline__ void strip_chain_task(const StripArgs &a, const Strip
     int e = min(a.w_ws[li], rlen - 1);  // column of the cell to reach: the winning cell, then the entry columns
     float want = a.w_score[li];         // ... and its cost
     int t_end = -1, t_st = -1;
+    int seen_rows = 0, seen_cols = 0;  // of the strips traced so far: rows and the columns the path took through them
     StripResult res;
     res.top.init();
     for (int sidx = n_strips - 1; sidx >= 0; --sidx) {
@@ -581,7 +582,12 @@ __device__ __forceinline__ void strip_chain_task(const StripArgs &a, const Strip
         strip_rows<R>(a, rd, sidx, lane, x);
         const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
         float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * kCkRec;
-        const int from = e - (a.trace_margin >= 0 ? a.trace_margin : nrows + 64);
+        // head start: as many columns as the strip has rows (+ 64) -- or, once the strips below have shown how many columns this
+        // read's path takes per row (event detection over-segments: 1.5 events per reference position are typical, i.e. 2/3 of a
+        // column per row), that many for this strip's rows + 25 % + 64.  Too short a head start only costs the back-off.
+        int margin = nrows + 64;
+        if (seen_rows >= 256) margin = min(margin, static_cast<int>((static_cast<int64_t>(seen_cols) * nrows * 5) / (static_cast<int64_t>(seen_rows) * 4)) + 64);
+        const int from = e - (a.trace_margin >= 0 ? a.trace_margin : margin);
         int k = from > 0 ? min(from >> a.ck_shift, nck) : 0, back = 1, b = -1, hit = -1;
         for (int attempt = 0; attempt < 40; ++attempt) {  // until the entry is known (k reaches 0 after <= 32 halvings)
             res.cap_end = -1;
@@ -606,6 +612,8 @@ __device__ __forceinline__ void strip_chain_task(const StripArgs &a, const Strip
         if (sidx == 0) {
             t_st = b;
         } else {
+            seen_rows += nrows;
+            seen_cols += e - b + 1;
             e = b;
             want = bin_c[b];
         }
