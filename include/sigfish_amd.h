@@ -174,6 +174,9 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
  * always, 0 = always as its own launch), "strip_pipeline" (long queries: 1 = default, the row strips of pass 1 run as one
  * pipelined launch; 0 = one wave per (read, contig, strand)), "strip_chain" (long queries: 1 = default, pass 2 traces the
  * strips from the last one upwards, each over its own short range of columns; 0 = all strips over the whole range),
+ * "balanced_strips" (long queries: 1 = default, the strips of a query have equal height, 64 lanes x {20, 24, 28, 32} rows
+ * by query length; 0 = 64 x 32 rows and a short last strip), "long_overlap" (1 = default: the row strips of a batch's long
+ * queries run on their own stream beside the wave kernels of its other reads; 0 = behind them),
  * "waves_per_simd" (1..8, occupancy target used when splitting the contig list), "lane_widening" (0 = auto by batch
  * size, 1/2/4 = fixed: rows per lane / w and lanes per read * w, the small-batch latency shapes), "widen_below"
  * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 5), "min_slice_reads" (a batch whose
