@@ -81,7 +81,9 @@ typedef struct sfa_ctx sfa_ctx_t;
 
 /* Device-side timing of the last call (HIP events recorded on the stream the kernels run on). */
 typedef struct {
-    double fill_ms;        /* pass 1: sdtw_fill_kernel (the dominant kernel) */
+    double fill_ms;        /* pass 1: sdtw_fill_kernel (the dominant kernel).  A batch with queries beyond 2048 events runs their
+                              row strips on a second stream beside the other kernels ("long_overlap"): the stages then overlap,
+                              fill_ms is the device time of the whole batch (= total_ms) and trace_ms is 0 */
     double trace_ms;       /* pass 2: sdtw_trace_kernel (start-column recovery of the winners) */
     double finalize_ms;    /* per-read reductions / row assembly */
     double total_ms;       /* first kernel start -> last kernel end */

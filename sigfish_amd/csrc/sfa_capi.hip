@@ -784,6 +784,10 @@ int resolve_profile(sfa_ctx *c) {
         float l = 0;
         HIP_TRY(hipEventElapsedTime(&l, c->ev[5], c->ev[4]));
         a += l;
+        if (c->opt_long_overlap) {  // ... and ran BESIDE the wave kernels: the intervals on this stream say nothing about stages
+            a = t;
+            d = 0;
+        }
         c->long_pending = false;
     }
     c->prof.events_ms = c->prof.normalise_ms = 0;

@@ -9,5 +9,6 @@ run --workload ncov_r9_dna_q250 --opt single_pass=1
 run --workload ncov_r9_dna_q500
 run --workload ncov_r9_dna_q1000
 run --workload ncov_r9_dna_q2000
+run --workload ncov_r9_dna_q3000
 run --workload ncov_r9_dna_q4000
 run --workload ncov_r9_dna_q8000
