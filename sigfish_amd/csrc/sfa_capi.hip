@@ -290,12 +290,13 @@ void launch_trace_lck(int maxr, const DpArgs &a, int32_t *out_st, hipStream_t st
 int resolve_profile(sfa_ctx *c);
 int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32_t n, ResultRow *d_out);
 
-// Reads of more than SFA_MAX_QUERY events: row strips (sdtw_strips.hpp).  Pass 1, one wave per (read, job), sweeps the
-// query in strips of 2048 rows, cost only, handing the last row of a strip to the next one through HBM; the strip finalize
-// names each read's winning (job, window, score); pass 2, one wave per read, sweeps the winning job again with start-column
-// tracking up to the end of the winning window.  Runs after the wave kernels of the batch, on the same stream, and
-// overwrites the (invalid) rows they left for these reads.  Reads are taken in groups whose boundary rows fit the
-// checkpoint budget.
+// Reads of more than SFA_MAX_QUERY events: row strips (sdtw_strips.hpp).  Pass 1, one wave per (read, job, strip) -- or per
+// (read, job) with "strip_pipeline" 0 --, sweeps the query in strips of 64 x R rows, cost only, handing the last row of a strip
+// to the next one through HBM; the strip finalize names each read's winning (job, cell, score); pass 2, one wave per read,
+// traces the winning job strip by strip from the last one upwards (or, "strip_chain" 0, all strips again up to the winning
+// cell) with start-column tracking.  Runs on `st`: the context's second stream, beside the wave kernels of the batch
+// ("long_overlap"), or its main stream behind them; it writes the rows of these reads, which the wave kernels' finalize leaves
+// alone.  Reads are taken in groups whose boundary rows and checkpoints fit the checkpoint budget.
 int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const int64_t *q_off_host, const std::vector<int32_t> &reads, int64_t max_qlen,
                ResultRow *d_out, hipStream_t st) {
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
