@@ -36,6 +36,32 @@ def test_sharded_rows_equal_single_device_rows(wl, n, devices, oracle):
     assert got[:m].tobytes() == oracle.align_batch(q, q_off[:m + 1], oref, flag, threads=4).tobytes()
 
 
+def test_sharded_batch_with_long_queries(oracle):
+    """Queries beyond 2048 events (row strips, on each shard's second stream beside its wave kernels) mixed with ordinary ones,
+    sharded over three contexts on one GPU: rows equal to one device's and to the oracle's."""
+    ref, flag, _, _, _ = synth.workload("ncov_r9_dna_q250", n_reads=8, seed=0)
+    rng = np.random.default_rng(21)
+    qlens = np.array([2500, 250, 3000, 2049, 100, 4500, 250, 2560, 0, 5000, 250])
+    q_off = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64)
+    q = np.empty(int(q_off[-1]), np.float32)
+    for i, l in enumerate(qlens):
+        if l == 0:
+            continue
+        src = ref.forward[0] if i % 2 == 0 else ref.reverse[0]
+        st = int(rng.integers(0, len(src) - l))
+        seg = src[st:st + l] + rng.normal(scale=0.3, size=l).astype(np.float32)
+        q[q_off[i]:q_off[i + 1]] = ((seg - seg.mean()) / seg.std()).astype(np.float32)
+    oref = oracle.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
+    want = oracle.align_batch(q, q_off, oref, flag, threads=8)
+    with S.Aligner(ref, flag, device=0) as one, S.Aligner(ref, flag, devices=[0, 0, 0]) as many:
+        a = one.align_db(q, q_off)
+        b = many.align_db(q, q_off)
+        again = many.align_db(q, q_off)
+    assert a.tobytes() == b.tobytes() == again.tobytes()
+    v = want["valid"] == 1
+    assert np.array_equal(a["valid"], want["valid"]) and a[v].tobytes() == want[v].tobytes()
+
+
 def test_sharded_align_events_and_raw():
     from tests.util import load_case
     from tests.test_host_stages import _pipeline
