@@ -212,6 +212,15 @@ struct Vec {
     typedef T type __attribute__((ext_vector_type(R)));
 };
 
+// Shapes with 32 rows per lane (queries of 257 .. 2048 events): the cost-only pass 1 names the winning CELL -- the column of the
+// first strict minimum of every window (src/sigfish.c:892-899), two operations per step of ~100 -- instead of the window alone,
+// so that pass 2 starts a query length in front of that cell rather than in front of its window: a quarter to a third of its
+// steps.  (The 16-row shapes cannot afford two more operations on 49; their pass 2 keeps scanning the window.)
+template <int R, bool TRACK, bool STD>
+struct CellFromFill {
+    static constexpr bool value = !TRACK && !STD && R >= 32;
+};
+
 // Running top-2 of the reference's candidate list for one read (kept in the registers of the lane that owns
 // the last query row).  Insertion rule of update_aln (src/sigfish.c:577-583): a candidate goes in front of
 // everything that is not strictly better, so on equal scores the LATER candidate ranks higher.
@@ -531,21 +540,25 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         if (!TRACK) pr.at_window(col);
         const int wl = STD ? rlen : min(qlen, rlen - col);  // std_dtw has a single candidate: one "window"
         const int nb = wl >> 2, rm = wl & 3;
+        constexpr bool CELL = CellFromFill<R, TRACK, STD>::value;
         float wmin = INFINITY;
-        int wpos = -1, wst = -1;
-        // Cost-only pass: only the window MINIMUM is kept (one v_min per step).  Which column attains it first is
-        // settled in pass 2 for the single window that wins.  With tracking (single-pass mode) the first strict
-        // minimum, its column and its start column are selected here, as src/sigfish.c:892-899 does.
+        int wpos = CELL ? col : -1, wst = -1;
+        // Cost-only pass, 16-row shapes: only the window MINIMUM is kept (one v_min per step); which column attains it first
+        // is settled in pass 2 for the single window that wins.  32-row shapes (CELL) also keep the column of the first strict
+        // minimum.  With tracking (single-pass mode) the first strict minimum, its column and its start column are selected
+        // here, as src/sigfish.c:892-899 does.
         auto track = [&]() {
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
-            if (!TRACK) {
+            if (!TRACK && !CELL) {
                 wmin = fminf(wmin, cl);
             } else {
                 const bool lt = cl < wmin;
                 wmin = lt ? cl : wmin;
                 wpos = lt ? jqv : wpos;
-                const int sl = (RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq]);
-                wst = lt ? sl : wst;
+                if (TRACK) {
+                    const int sl = (RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq]);
+                    wst = lt ? sl : wst;
+                }
                 jqv += 1;
             }
         };
@@ -585,7 +598,8 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             ycur = ynext;
         }
         if (!STD) {
-            const bool became_best = top.offer(wmin, TRACK ? wpos : col, wst, job);  // cost-only: the window is identified by its first column
+            // (cost-only, 16-row shapes: the window is identified by its first column)
+            const bool became_best = top.offer(wmin, (TRACK || CELL) ? wpos : col, wst, job);
             if (LCK) {
                 const unsigned long long improved = __ballot(became_best && owner);
                 if (improved) lck->template save<R, L, WT>(improved, wmin, col + e_main, a.trace_margin, lq, job);
@@ -784,10 +798,19 @@ __device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, 
         if (col == col_real && vin) snapshot(vin);
         const int wl = min(qlen, rlen - col);
         const int nb = wl >> 2, rm = wl & 3;
+        constexpr bool CELL = CellFromFill<R, false, false>::value;
         float wmin = INFINITY;
+        int wpos = col, jq = col;  // (CELL) column of the window's first strict minimum / of the next last-row cell
         auto track = [&]() {
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
-            wmin = fminf(wmin, cl);
+            if (!CELL) {
+                wmin = fminf(wmin, cl);
+            } else {
+                const bool lt = cl < wmin;
+                wmin = lt ? cl : wmin;
+                wpos = lt ? jq : wpos;
+                jq += 1;
+            }
         };
         auto block = [&](const float4u &yv) {
             maybe_checkpoint();
@@ -816,7 +839,7 @@ __device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, 
             e += rm;
             ycur = ynext;
         }
-        if (col >= col_real) top.offer(wmin, col, -1, job);
+        if (col >= col_real) top.offer(wmin, CELL ? wpos : col, -1, job);
         col += wl;
     }
     if (vout) snapshot(vout);
@@ -1048,7 +1071,8 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
 
     int job = (read >= 0) ? w.job : -1;
-    const int ws = (read >= 0) ? w.ws : 0;  // first column of the winning window
+    constexpr bool CELL = CellFromFill<R, false, STD>::value && !LCK;
+    const int ws = (read >= 0) ? w.ws : 0;  // first column of the winning window; CELL: the column of the winning cell itself
     const float best = (read >= 0) ? w.best : 0.0f;
     bool done = !(read >= 0 && job >= 0 && ws >= 0);
     job = done ? 0 : job;
@@ -1057,7 +1081,7 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     const int t_begin = sweep_begin(lq);             // same time origin as the fill
     const float *ybase = a.ref + a.job_off[job] - g;
     const int t_first = ws + lq;            // step at which lane lq evaluates the first cell of the window
-    const int t_last = ws + wl - 1 + lq;    // ... and the last one
+    const int t_last = CELL ? t_first : ws + wl - 1 + lq;  // ... and the last one
 
     const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
     const int64_t ck_total = a.ck_shift ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
