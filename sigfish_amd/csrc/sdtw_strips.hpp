@@ -82,7 +82,7 @@ struct StripArgs {
 };
 
 #ifndef SFA_PIPE_BLOCK
-#define SFA_PIPE_BLOCK 512
+#define SFA_PIPE_BLOCK 256
 #endif
 constexpr int kPipeBlock = SFA_PIPE_BLOCK;  // columns between two hand-overs of a boundary row (one release / acquire pair each)
 
