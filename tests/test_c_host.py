@@ -100,3 +100,20 @@ def test_device_inflate_lane_decoder_on_the_host_with_sanitizers(tmp_path):
     assert build.returncode == 0, build.stderr.decode()[-2000:]
     run = subprocess.run([exe, "4000", "3"], capture_output=True, timeout=900)
     assert run.returncode == 0 and b"4000 iterations, 0 failures" in run.stdout, (run.stdout + run.stderr).decode()[-3000:]
+
+
+def test_strip_heights_cover_every_query_length(tmp_path):
+    """sfa::strip_rows_per_lane (sdtw_strips.hpp), compiled for the host with hipcc: for every query length from 2049 to 400 000
+    events the strips cover the query, the last one holds at least one row, the height is an instantiated one -- a violation
+    would index rows outside the query on the device."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "strip_rows")
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "sigfish_amd", "csrc"), "-o", exe,
+                            os.path.join(ROOT, "tests", "c", "strip_rows_host.hip")], capture_output=True, timeout=600)
+    assert build.returncode == 0, build.stderr.decode()[-2000:]
+    run = subprocess.run([exe], capture_output=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.startswith(b"0 violations"), (run.stdout + run.stderr).decode()
+    assert b"0.800" in run.stdout  # at least 80 % of the rows of any query's strips are query rows
