@@ -21,4 +21,10 @@ SFA_FOR_MAXR(SFA_TRACE_DECL, true)
     extern template __global__ void sdtw_fill_kernel<MR, false, false, false, true, true>(const DpArgs); \
     extern template __global__ void sdtw_trace_kernel<MR, false, true>(const DpArgs, int32_t *);
 SFA_LCK_DECL(4) SFA_LCK_DECL(8) SFA_LCK_DECL(16)
+// ... and for std_dtw (no LDS snapshots, sparse HBM store; pass 2 by ticket): sdtw_inst_lckstd16.hip
+#define SFA_LCKSTD_DECL(MR)                                                                           \
+    extern template __global__ void sdtw_fill_kernel<MR, false, true, false, true>(const DpArgs);     \
+    extern template __global__ void sdtw_fill_kernel<MR, false, true, false, true, true>(const DpArgs); \
+    extern template __global__ void sdtw_trace_kernel<MR, true, true>(const DpArgs, int32_t *);
+SFA_LCKSTD_DECL(4) SFA_LCKSTD_DECL(8) SFA_LCKSTD_DECL(16)
 }  // namespace sfa

@@ -146,6 +146,11 @@ struct DpArgs {
     // 0 = off; `started` counts the tasks that have begun (zeroed before the launch)
     int32_t prio_unit;
     unsigned *started;
+    // bounded waits (see bounded_wait_ge): error words of the launch, limit in 100 MHz ticks; debug_drop_quad >= 0: the fill
+    // tasks of that quad do not count themselves in (a never-published quad, for the test of the bound)
+    unsigned *err;
+    long long spin_limit;
+    int32_t debug_drop_quad;
     unsigned long long *task_times;  // -DSFA_TASK_TIMES builds only (tools/task_times.py): [task][3] start, end (100 MHz ticks), SIMD position
 };
 
@@ -157,6 +162,50 @@ __device__ __forceinline__ unsigned simd_position() {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID[3:0]
     const unsigned simd = (hw >> 4) & 3, cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
     return ((((xcc & 15) * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd;
+}
+
+// ---- hand-over between waves of ONE launch (fused pass 2, pipelined row strips) ----------------------------------------
+// Producer: every byte the consumer will read is stored WRITE-THROUGH (global_store ... sc1: relaxed agent-scope atomic
+// stores, or inline asm for the 16-byte rows), then the storing wave waits for its own stores -- drain_stores() -- and only
+// then bumps the counter / progress word the consumer polls.  The wait is INLINE ASM on purpose: a workgroup-scope release
+// fence emits no vmcnt wait at all on gfx950 / ROCm 7.2 (round 2 relied on it: the counter could overtake the stores), and
+// the compiler may drop the wait of an agent-scope fence when it believes the scoreboard empty; the asm statement is
+// invisible to that pass and a compiler barrier for memory operations.  tests/test_publish_isa.py disassembles the shipped
+// kernels and checks stores (sc1), wait and counter are there in this order.  The agent-scope release fence itself
+// (buffer_wbl2) is what this avoids: it writes the whole L2 of the XCD back at the end of every task.
+// Consumer: relaxed poll of the counter, agent-scope acquire (buffer_inv sc1), then plain loads.
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// A wait that never ends is a hung stream and, on this pool, a lost box.  Every spin of a launch is bounded by wall-clock
+// time (s_memrealtime: 100 MHz): when the limit passes the wave records what it waited for in the launch's error words,
+// gives up, and the host returns SFA_EKERNEL for the batch (rows are not to be used).  err[0] = code (first error wins),
+// err[1], err[2] = detail.
+constexpr unsigned kErrQuadWait = 1;   // fused launch: pass 2 of quad err[1] never saw its fill tasks complete (err[2] = count seen)
+constexpr unsigned kErrStripWait = 2;  // pipelined strips: a strip never saw the row above reach column err[1] (err[2] = column seen)
+__device__ __forceinline__ void report_device_error(unsigned *err, unsigned code, int d1, int d2) {
+    if (atomicCAS(err, 0u, code) == 0u) {
+        (void)__hip_atomic_exchange(err + 1, static_cast<unsigned>(d1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_exchange(err + 2, static_cast<unsigned>(d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// lane 0 polls *ctr until it is >= need; returns false (all lanes) when `limit` ticks have passed.  sleep: s_sleep argument
+__device__ __forceinline__ bool bounded_wait_ge(const int32_t *ctr, const int need, const long long limit, int *seen, const bool long_sleep) {
+    int ok = 1, v = 0;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while ((v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+            if (long_sleep)
+                __builtin_amdgcn_s_sleep(127);
+            else
+                __builtin_amdgcn_s_sleep(16);
+            if (static_cast<long long>(wall_clock64() - t0) > limit) {
+                ok = 0;
+                break;
+            }
+        }
+    }
+    *seen = __builtin_amdgcn_readfirstlane(v);
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
 // Neighbour exchange.  Lane g needs the bottom cost lane g-1 produced in the previous step.  On gfx950 a
@@ -482,12 +531,16 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     int e = 0;               // steps executed so far; the next step is t = t_begin + e
     int ck_next = T ? T : 0x7fffffff;
     const int ck_last = T ? ((rlen > 4 ? rlen - 4 : 0) >> a.ck_shift) << a.ck_shift : 0;  // last k*T that is stored
-    if (LCK) {
+    // LCK with std_dtw: no LDS snapshots at all (SNAP false) -- the single candidate of a job is its LAST cell and its path may
+    // begin anywhere in the strand, so the state a few hundred steps in front of it is no use; pass 2 starts from the sparse HBM
+    // store (interval T, tens of thousands of steps) or from the start of the strand, which for a transcriptome is the same
+    constexpr bool SNAP = LCK && !STD;
+    if (SNAP) {
         lck->begin_job();
         ck_next = 1 << kLdsCkShift;
     }
     auto maybe_checkpoint = [&]() {  // at a block boundary: snapshot the state BEFORE step t_begin + e
-        if (LCK) {
+        if (SNAP) {
             if (e >= ck_next) {
                 lck->template snapshot<R>(cv, dprev, e);
                 ck_next += 1 << kLdsCkShift;
@@ -511,10 +564,17 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             }
         } else if (!TRACK && T) {
             if (e >= ck_next && ck_next <= ck_last) {
+                if (WT) {  // read by the pass-2 waves of the same launch
 #pragma unroll
-                for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
-                ckp[R * 64] = dprev;
-                ckp[(R + 1) * 64] = __int_as_float(e);
+                    for (int r = 0; r < R; ++r) __hip_atomic_store(ckp + r * 64, static_cast<float>(cv[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ckp + R * 64, dprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ckp + (R + 1) * 64, __int_as_float(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
+                    ckp[R * 64] = dprev;
+                    ckp[(R + 1) * 64] = __int_as_float(e);
+                }
                 ckp += ck_planes<R>() * 64;
                 ck_next += T;
             }
@@ -674,7 +734,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         pr.start(on ? a.prio_unit : 0, cols, FUSED ? a.ticket : a.started, static_cast<unsigned>(a.n_tasks), !FUSED);
     }
     LdsCkpt lck;
-    if (LCK) {
+    if (LCK && !STD) {
         const int64_t task = static_cast<int64_t>(quad) * a.n_chunks + chunk;
         lck.buf = lds_ck + (threadIdx.x >> 6) * (2 * kLdsCkPlanes * 64) + lane;
         lck.rec = a.best_rec + task * a.best_planes * 64 + lane;
@@ -712,13 +772,12 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         }
     }
     if (FUSED) {
-        // Partial results and best-window records of this task are complete: publish, then count the quad's task in.  Everything
-        // a pass-2 wave will read was stored WRITE-THROUGH (agent-scope atomic stores: global_store ... sc1), so all that is
-        // left to do is to wait for those stores (a workgroup-scope release is exactly s_waitcnt vmcnt(0)).  The textbook
-        // agent-scope release fence would write back the whole L2 of the XCD at the end of every one of 50 000 tasks:
-        // measured as 2.07 GB of WRITE_SIZE per launch instead of 0.3 (profiles/r02_v2 vs r02_v3).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(a.quad_done + quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Partial results, best-window records and sparse checkpoints of this task are complete and were all stored
+        // write-through; wait for them, then count the quad's task in (see drain_stores()).  The textbook agent-scope release
+        // fence would write back the whole L2 of the XCD at the end of every one of 50 000 tasks: measured as 2.07 GB of
+        // WRITE_SIZE per launch instead of 0.3 (profiles/r02_v2 vs r02_v3).
+        drain_stores();
+        if (lane == 0 && quad != a.debug_drop_quad) __hip_atomic_fetch_add(a.quad_done + quad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         set_issue_priority(0);
     }
 #ifdef SFA_TASK_TIMES
@@ -931,7 +990,7 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 // the fill loops would then read `a.xyz` from there, per lane, instead of from scalar registers -- measured as a scratch
 // load in every block of four steps; passing the 600-byte block by value costs a per-LANE stack copy per call instead,
 // 0.95 GB of scratch writes per 100 000-read launch)
-template <int MAXR>
+template <int MAXR, bool STD>
 __device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i);
 
 // LCK: rolling checkpoints in LDS (LdsCkpt) -- two snapshots of 17 planes per wave, 34 KB per block, four blocks per CU.
@@ -946,7 +1005,7 @@ __device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa,
 template <int MAXR, bool TRACK, bool STD, bool SEG = false, bool LCK = false, bool FUSED = false>
 __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES)))) sdtw_fill_kernel(const DpArgs a) {
     static_assert(!SEG || (!TRACK && !STD), "segments: cost-only subsequence DTW");
-    static_assert(!LCK || (!TRACK && !STD && !SEG && MAXR <= 16), "LDS checkpoints: cost-only subsequence DTW, R <= 16");
+    static_assert(!LCK || (!TRACK && !SEG && MAXR <= 16), "LDS checkpoints: the cost-only fill, R <= 16 (std_dtw: sparse HBM store only)");
     static_assert(!FUSED || LCK, "the fused launch is built on the LDS-checkpoint fill");
     // blockIdx -> task.  Blocks are dealt to the 8 XCDs round-robin, so with the identity every XCD sees every class and
     // every chunk of the job list evenly -- what this kernel wants: the reference arrays (hundreds of KB to a few MB) stay
@@ -969,7 +1028,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
     int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
     __shared__ float lds_f[4 * kXchWordsPerWave];
     __shared__ int lds_i[(TRACK || FUSED) ? 4 * kXchWordsPerWave : 1];
-    __shared__ float lds_ck[LCK ? 4 * 2 * kLdsCkPlanes * 64 : 1];
+    __shared__ float lds_ck[(LCK && !STD) ? 4 * 2 * kLdsCkPlanes * 64 : 1];
     // FUSED with SFA_FUSED_PERSIST: a wave works through tickets until they run out instead of leaving its slot to a new block
     for (;;) {
         if (FUSED) {
@@ -979,7 +1038,7 @@ __global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR 
             if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
                 const int quad = task - a.n_tasks;
                 if (quad >= a.n_quads_total) return;
-                fused_trace_dispatch<MAXR>(a.self, quad, lds_f, lds_i);
+                fused_trace_dispatch<MAXR, STD>(a.self, quad, lds_f, lds_i);
                 if (SFA_FUSED_PERSIST) continue;
                 return;
             }
@@ -1102,7 +1161,7 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     bool use_rec = false;
     const float *recp = nullptr;
     int rec_e = -1;
-    if (LCK && !done) {
+    if (LCK && !STD && !done) {  // (std_dtw keeps no records: k, into the sparse store, stands)
         const int64_t task = static_cast<int64_t>(quad) * a.n_chunks + w.chunk;
         rec_e = a.best_e[task * 4 + slot];
         recp = a.best_rec + task * a.best_planes * 64 + lane;
@@ -1268,18 +1327,21 @@ __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
     return static_cast<uint8_t>(q);
 }
 
-template <int R, int L>
+template <int R, int L, bool STD>
 __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDesc cd, const int quad_local, float *lds_f, int *lds_i) {
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
     const int g = lane & (L - 1);
     const int slot = lane / L;
     // every fill task of the quad must have published its results (they hold lower tickets: running or finished)
-    if (lane == 0) {
-        while (__hip_atomic_load(a.quad_done + quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.n_chunks) __builtin_amdgcn_s_sleep(127);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int seen;
+    const bool arrived = bounded_wait_ge(a.quad_done + quad, a.n_chunks, a.spin_limit, &seen, true);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (on the give-up path too: every load behind the poll is behind the acquire)
     __builtin_amdgcn_wave_barrier();
+    if (!arrived) {
+        if (lane == 0) report_device_error(a.err, kErrQuadWait, quad, seen);
+        return;  // wave-uniform; the host reports SFA_EKERNEL for the batch
+    }
     const int qlen = a.quad_qlen[quad];
     const int lq = (qlen - 1) / R;
     const int read = a.order[quad * 4 + slot];
@@ -1336,7 +1398,7 @@ __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDes
     w.best = __shfl(w.best, src);
     w.chunk = __shfl(w.chunk, src);
     int res_st, res_end;
-    trace_core<R, L, false, true>(a, cd, quad_local, w, lds_f, lds_i, res_st, res_end);
+    trace_core<R, L, STD, true>(a, cd, quad_local, w, lds_f, lds_i, res_st, res_end);
     if (owner) {
         if (r.rid >= 0) {  // src/sigfish.c:971-975
             const int rl = a.ref_len[r.rid], off = a.ref_st_offset[r.rid];
@@ -1347,7 +1409,7 @@ __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDes
     }
 }
 
-template <int MAXR>
+template <int MAXR, bool STD>
 __device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i) {
     const DpArgs &a = *pa;
     int ci = 0;
@@ -1356,7 +1418,7 @@ __device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa,
     const int ql = quad - cd.quad_base;
 #define SFA_TSHAPE(RR, LL)                                                               \
     case (RR) * 256 + (LL):                                                              \
-        if constexpr (MAXR >= (RR)) fused_trace_task<RR, LL>(a, cd, ql, lds_f, lds_i);    \
+        if constexpr (MAXR >= (RR)) fused_trace_task<RR, LL, STD>(a, cd, ql, lds_f, lds_i); \
         break;
     switch (cd.R * 256 + cd.lanes) {
         SFA_TSHAPE(16, 64) SFA_TSHAPE(16, 32) SFA_TSHAPE(16, 16)

@@ -79,6 +79,11 @@ struct StripArgs {
     unsigned *ticket;           // task counter (zeroed before the launch)
     int32_t balanced;           // 1: rows per lane by query length (strip_rows_per_lane), 0: always 32
     int32_t keep_rows;          // classic pass 1: 1 = strip s writes boundary row s (bnd_stride rows per read) instead of two rows in turn
+    // bounded waits (sdtw_kernels.hpp, bounded_wait_ge): error words, limit in 100 MHz ticks; debug_drop_strip >= 0: strip 0 of
+    // that (long read of the group, job 0) publishes no progress (for the test of the bound)
+    unsigned *err;
+    long long spin_limit;
+    int32_t debug_drop_strip;
 };
 
 #ifndef SFA_PIPE_BLOCK
@@ -136,7 +141,7 @@ __device__ __forceinline__ void strip_step(typename Vec<float, R>::type &c, type
 
 // Four columns of a boundary row.  `through`: the row is handed to another wave of the same launch (pipelined pass 1), maybe
 // on another XCD with its own L2: the store writes through to memory (sc1), so that the producer only has to wait for its own
-// stores (publish_fence) instead of writing back the whole L2 (a release fence at agent scope is buffer_wbl2 -- with 17 GB of
+// stores (publish_fence: an explicit s_waitcnt vmcnt(0)) instead of writing back the whole L2 (a release fence at agent scope is buffer_wbl2 -- with 17 GB of
 // checkpoints passing through the same L2, once per kPipeBlock columns and wave).
 #ifndef SFA_STRIP_WT
 #define SFA_STRIP_WT 1
@@ -149,11 +154,12 @@ __device__ __forceinline__ void store_row4(float *p, const typename Vec<float, 4
 }
 __device__ __forceinline__ void publish_fence() {
     if (SFA_STRIP_WT)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): this wave's write-through stores are in memory
-    else
+        drain_stores();  // explicit s_waitcnt vmcnt(0): this wave's write-through stores have completed (sdtw_kernels.hpp)
+    else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        drain_stores();  // (the compiler may drop the fence's own wait, see drain_stores())
+    }
 }
-
 
 // What the final strip reports.  Pass 1: the running top-2 over windows (by window).  Pass 2: the winning cell.
 struct StripResult {
@@ -163,14 +169,15 @@ struct StripResult {
 
 // One strip over columns [0, ncols) of one (contig,strand).  LAST: the strip holds the last query row (lane lq,
 // register rq).  Pass 2 (TRACK): [ws, ncols) is the winning window and `best` its minimum.
-template <bool STD, bool FIRST, bool TRACK, bool CHAIN, bool LAST, int R>
+template <bool STD, bool FIRST, bool TRACK, bool CHAIN, bool LAST, int R, bool PIPE = false>
 __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen,
                                             const float (&x)[R], const int lq, const int rq, const int lane, Exchange &xc,
                                             const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
                                             const int job, const int ws, const float best, const int t_begin, float *ckp,
-                                            const int ck_shift, const int nck, const int32_t *prog_in = nullptr, int32_t *prog_out = nullptr) {
-    // prog_in / prog_out (pipelined pass 1): how far the strip above has got with the row this sweep reads / where to say how
-    // far this sweep has got with the row it writes.  Both wave-uniform; nullptr: the rows are complete / nobody is waiting.
+                                            const int ck_shift, const int nck, const int32_t *prog_in = nullptr, int32_t *prog_out = nullptr,
+                                            unsigned *err = nullptr, const long long spin_limit = 0) {
+    // PIPE (pipelined pass 1), prog_in / prog_out: how far the strip above has got with the row this sweep reads / where to say
+    // how far this sweep has got with the row it writes.  Both wave-uniform.  !PIPE: the rows are complete / nobody is waiting.
     // ckp: this strip's checkpoint records (+ lane).  Pass 1 stores record k - 1 before step k*T; pass 2 resumes from the
     // record of step t_begin (t_begin = 0: from the initial state).
     typename Vec<float, R>::type c;
@@ -217,13 +224,19 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     int wait_next = t_begin, pub_next = t_begin + kPipeBlock;
     auto wait_for_row = [&](int t0) {
         const int need = min(ncols, t0 + kPipeBlock + 72);
-        if (lane == 0)
-            while (__hip_atomic_load(prog_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
+        int seen;
+        wait_next = t0 + kPipeBlock;
+        const bool arrived = bounded_wait_ge(prog_in, need, spin_limit, &seen, false);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        wait_next = t0 + kPipeBlock;
+        if (!arrived) {
+            // the row above never got there: say so and walk on without waiting any more (the batch is reported as failed; the
+            // strips below still see this one's progress and end as well)
+            if (lane == 0) report_device_error(err, kErrStripWait, need, seen);
+            wait_next = 0x7fffffff;
+        }
     };
-    if (!FIRST && prog_in) wait_for_row(t_begin);
+    if (PIPE && !FIRST) wait_for_row(t_begin);
     float4u ycur = *reinterpret_cast<const float4u *>(yp + t_begin);
     // The row above, 64 columns at a time: lane l holds column (chunk base) + l, the next chunk is in flight while this one is
     // used (64 steps: a boundary row another wave has just written through comes from HBM, not from this XCD's L2), and
@@ -240,8 +253,8 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
         // per block in the steady state
         const bool housekeeping = cpos == 0 || (T < 64 && (t0 & (T - 1)) == 0);
         if (!TRACK && __builtin_expect(housekeeping, 0)) {
-            if (!FIRST && prog_in && t0 >= wait_next) wait_for_row(t0);
-            if (prog_out && t0 >= pub_next) {  // the stores of the columns below t0 - 64 have reached memory, then the counter says so
+            if (PIPE && !FIRST && t0 >= wait_next) wait_for_row(t0);
+            if (PIPE && !LAST && t0 >= pub_next) {  // the stores of the columns below t0 - 64 have reached memory, then the counter says so
                 publish_fence();
                 if (lane == 0) __hip_atomic_store(prog_out, t0 - 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pub_next = t0 + kPipeBlock;
@@ -284,7 +297,7 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                 // lane 63 is at column t - 63 of the strip's last row; t0 is a multiple of 4, so the column is u + 1 (mod 4):
                 // four columns are collected and stored as one aligned 16-byte word when the fourth arrives
                 ob[(u + 1) & 3] = c[R - 1];
-                if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob, prog_out != nullptr);
+                if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob, PIPE);
             } else if (!LAST) {
                 const int col = t - 63;
                 if (lane == 63 && col >= 0 && col < ncols) {
@@ -317,7 +330,7 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
         }
         ycur = ynext;
     }
-    if (!TRACK && prog_out) {  // the whole row is there
+    if (PIPE && !LAST) {  // the whole row is there
         publish_fence();
         if (lane == 0) __hip_atomic_store(prog_out, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -500,15 +513,17 @@ __device__ __forceinline__ void strip_pipe_task(const StripArgs &a, const StripR
     res.cap_st = -1;
     float *bout_c = last ? nullptr : rows + static_cast<int64_t>(sidx) * per;
     const float *bin_c = sidx > 0 ? rows + static_cast<int64_t>(sidx - 1) * per : nullptr;
-    if (sidx == 0)  // (queries of this path have more than one strip: the first is never the last)
-        strip_sweep<STD, true, false, false, false, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f, 0,
-                                                       ckp, a.ck_shift, nck, nullptr, prog + sidx);
-    else if (!last)
-        strip_sweep<STD, false, false, false, false, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0, 0.0f,
-                                                        0, ckp, a.ck_shift, nck, prog + sidx - 1, prog + sidx);
+    if (sidx == 0) {  // (queries of this path have more than one strip: the first is never the last)
+        // (test hook: the dropped strip publishes into a word nobody reads)
+        int32_t *pub = (li == a.debug_drop_strip && job == 0) ? reinterpret_cast<int32_t *>(a.ticket + 8) : prog + sidx;
+        strip_sweep<STD, true, false, false, false, R, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0,
+                                                             0.0f, 0, ckp, a.ck_shift, nck, nullptr, pub);
+    } else if (!last)
+        strip_sweep<STD, false, false, false, false, R, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0,
+                                                              0.0f, 0, ckp, a.ck_shift, nck, prog + sidx - 1, prog + sidx, a.err, a.spin_limit);
     else
-        strip_sweep<STD, false, false, false, true, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, 0, 0.0f,
-                                                       0, ckp, a.ck_shift, nck, prog + sidx - 1, nullptr);
+        strip_sweep<STD, false, false, false, true, R, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, 0,
+                                                             0.0f, 0, ckp, a.ck_shift, nck, prog + sidx - 1, nullptr, a.err, a.spin_limit);
     if (last && lane == lq) {
         const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
         a.p_best[o] = res.top.best;

@@ -150,6 +150,9 @@ struct sfa_ctx {
     int64_t opt_fused_trace = 1;             // 1: with LDS checkpoints, pass 2 rides in the fill launch as trailing tickets (fills the drain)
     int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
     int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
+    int64_t opt_spin_limit_ms = 20000;       // bound of every in-launch wait (fused pass 2, pipelined strips); beyond it the batch fails with SFA_EKERNEL
+    int64_t opt_debug_drop_quad = -1;        // test hook: the fill tasks of this quad never signal completion
+    int64_t opt_debug_drop_strip = -1;       // test hook: strip 0 of this long read (job 0) never publishes its progress
 
     // reference model (immutable after init)
     int32_t num_ref = 0, n_jobs = 0;
@@ -250,18 +253,29 @@ void launch_trace(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipS
 #undef SFA_TRACE
 }
 
-// the variants with rolling checkpoints in LDS (cost-only subsequence DTW, R <= 16)
-void launch_fill_lck(int maxr, const DpArgs &a, hipStream_t st) {
+// the variants with rolling checkpoints in LDS (cost-only fill, R <= 16; std_dtw: the sparse HBM store alone)
+#define SFA_LCK_LAUNCH(KERNEL, ...)                                                       \
+    do {                                                                                  \
+        if (maxr >= 16)                                                                   \
+            hipLaunchKernelGGL((KERNEL(16)), grid, block, 0, st, __VA_ARGS__);            \
+        else if (maxr >= 8)                                                               \
+            hipLaunchKernelGGL((KERNEL(8)), grid, block, 0, st, __VA_ARGS__);             \
+        else                                                                              \
+            hipLaunchKernelGGL((KERNEL(4)), grid, block, 0, st, __VA_ARGS__);             \
+    } while (0)
+void launch_fill_lck(int maxr, bool std_dtw, const DpArgs &a, hipStream_t st) {
     const dim3 grid((a.n_tasks + 3) / 4), block(256);
-    if (maxr >= 16)
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<16, false, false, false, true>), grid, block, 0, st, a);
-    else if (maxr >= 8)
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<8, false, false, false, true>), grid, block, 0, st, a);
+#define K_(MR) sfa::sdtw_fill_kernel<MR, false, false, false, true>
+#define KS_(MR) sfa::sdtw_fill_kernel<MR, false, true, false, true>
+    if (std_dtw)
+        SFA_LCK_LAUNCH(KS_, a);
     else
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, false, true>), grid, block, 0, st, a);
+        SFA_LCK_LAUNCH(K_, a);
+#undef K_
+#undef KS_
 }
 
-void launch_fill_fused(int maxr, const DpArgs &a, hipStream_t st, int cu_count) {  // fill tasks + one pass-2 ticket per quad
+void launch_fill_fused(int maxr, bool std_dtw, const DpArgs &a, hipStream_t st, int cu_count) {  // fill tasks + one pass-2 ticket per quad
     // waves claim tickets until they run out: no more blocks than the device holds at once (four per CU: the LDS buffers), so
     // that none of them starts only to find the counter exhausted
     unsigned blocks = static_cast<unsigned>((a.n_tasks + 3) / 4 + (a.n_quads_total + 3) / 4);
@@ -269,22 +283,26 @@ void launch_fill_fused(int maxr, const DpArgs &a, hipStream_t st, int cu_count) 
     blocks = std::min<unsigned>(blocks, static_cast<unsigned>(cu_count) * SFA_LCK_WAVES);
 #endif
     const dim3 grid(blocks), block(256);
-    if (maxr >= 16)
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<16, false, false, false, true, true>), grid, block, 0, st, a);
-    else if (maxr >= 8)
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<8, false, false, false, true, true>), grid, block, 0, st, a);
+#define K_(MR) sfa::sdtw_fill_kernel<MR, false, false, false, true, true>
+#define KS_(MR) sfa::sdtw_fill_kernel<MR, false, true, false, true, true>
+    if (std_dtw)
+        SFA_LCK_LAUNCH(KS_, a);
     else
-        hipLaunchKernelGGL((sfa::sdtw_fill_kernel<4, false, false, false, true, true>), grid, block, 0, st, a);
+        SFA_LCK_LAUNCH(K_, a);
+#undef K_
+#undef KS_
 }
 
-void launch_trace_lck(int maxr, const DpArgs &a, int32_t *out_st, hipStream_t st) {
+void launch_trace_lck(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, hipStream_t st) {
     const dim3 grid((a.n_tasks + 3) / 4), block(256);
-    if (maxr >= 16)
-        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<16, false, true>), grid, block, 0, st, a, out_st);
-    else if (maxr >= 8)
-        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<8, false, true>), grid, block, 0, st, a, out_st);
+#define K_(MR) sfa::sdtw_trace_kernel<MR, false, true>
+#define KS_(MR) sfa::sdtw_trace_kernel<MR, true, true>
+    if (std_dtw)
+        SFA_LCK_LAUNCH(KS_, a, out_st);
     else
-        hipLaunchKernelGGL((sfa::sdtw_trace_kernel<4, false, true>), grid, block, 0, st, a, out_st);
+        SFA_LCK_LAUNCH(K_, a, out_st);
+#undef K_
+#undef KS_
 }
 
 int resolve_profile(sfa_ctx *c);
@@ -302,8 +320,8 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
     const size_t o_reads = 0, o_bnd = (sizeof(int32_t) * n_long + 7) & ~size_t(7);
     const size_t o_ck = o_bnd + sizeof(int64_t) * (n_jobs + 1);
-    const size_t o_soff = o_ck + sizeof(int64_t) * (n_jobs + 1);  // per-group prefix sums of the reads' strip counts (filled per group)
-    const size_t stage_bytes = o_soff + sizeof(int32_t) * (static_cast<size_t>(n_long) + 2);
+    const size_t o_soff = o_ck + sizeof(int64_t) * (n_jobs + 1);  // per-group prefix sums of the reads' strip counts: group g0 at word g0 + (its index)
+    const size_t stage_bytes = o_soff + sizeof(int32_t) * (2 * static_cast<size_t>(n_long) + 2);  // (at most n_long groups)
     std::vector<int32_t> n_strips_of(n_long);
     for (int32_t i = 0; i < n_long; ++i) n_strips_of[i] = static_cast<int32_t>((q_off_host[reads[i] + 1] - q_off_host[reads[i]] + sfa::kStripRows - 1) / sfa::kStripRows);
     int rc;
@@ -353,11 +371,20 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         (rc = c->d_lck.reserve(sizeof(float) * std::max<int64_t>(ck_floats_per_read, 1) * group)))
         return rc;
     if (c->d_bndc.cap != bndc_cap) HIP_TRY(hipMemsetAsync(c->d_bndc.p, 0x7f, c->d_bndc.cap, st));  // fresh allocation: 3.4e38 everywhere (see the pad note in sdtw_strips.hpp)
+    if (pipe) {  // the prefix sums of every group, each in its own words: one upload for all groups, no host wait between them
+        int32_t *soff = reinterpret_cast<int32_t *>(hs + o_soff);
+        for (int32_t g0 = 0, gi = 0; g0 < n_long; g0 += group, ++gi) {
+            const int32_t gn = std::min(group, n_long - g0);
+            int32_t *so = soff + g0 + gi;
+            so[0] = 0;
+            for (int32_t i = 0; i < gn; ++i) so[i + 1] = so[i] + n_strips_of[g0 + i];
+        }
+    }
     HIP_TRY(hipMemcpyAsync(c->d_long.p, hs, stage_bytes, hipMemcpyHostToDevice, st));
     const char *ds = c->d_long.as<char>();
     const bool std_dtw = (c->flag & SFA_DTW) != 0;
     int32_t *win = c->d_lwin.as<int32_t>();  // [5][n_long]: w_job, w_ws, w_score, t_st, t_end
-    for (int32_t g0 = 0; g0 < n_long; g0 += group) {
+    for (int32_t g0 = 0, gi = 0; g0 < n_long; g0 += group, ++gi) {
         const int32_t gn = std::min(group, n_long - g0);
         sfa::StripArgs sa{};
         sa.queries = d_queries;
@@ -389,6 +416,9 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.n_long = gn;
         sa.n_jobs = n_jobs;
         sa.rev_query = ((c->flag & SFA_RNA) && !(c->flag & SFA_INV)) ? 1 : 0;
+        sa.err = c->d_badcount.as<unsigned>() + 4;
+        sa.spin_limit = c->opt_spin_limit_ms * 100000;  // 100 MHz ticks
+        sa.debug_drop_strip = (c->opt_debug_drop_strip >= g0 && c->opt_debug_drop_strip < g0 + gn) ? static_cast<int32_t>(c->opt_debug_drop_strip - g0) : -1;
         sfa::StripFinalizeArgs fa{};
         fa.reads = sa.reads;
         fa.p_best = sa.p_best;
@@ -410,15 +440,10 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         const dim3 block(256), fgrid((gn + 63) / 64), fblock(64);
         const dim3 grid1(static_cast<unsigned>((static_cast<int64_t>(gn) * n_jobs + 3) / 4)), grid2((gn + 3) / 4);
         if (pipe) {  // one wave per (job, read, strip), tickets in that order
-            int32_t *soff = reinterpret_cast<int32_t *>(hs + o_soff);
-            soff[0] = 0;
-            for (int32_t i = 0; i < gn; ++i) soff[i + 1] = soff[i] + n_strips_of[g0 + i];
-            // (the staging area was uploaded before the loop; this group's prefix sums go up on their own, stream-ordered)
-            HIP_TRY(hipStreamSynchronize(st));  // the previous group may still be reading its copy
-            HIP_TRY(hipMemcpyAsync(const_cast<char *>(ds) + o_soff, soff, sizeof(int32_t) * (gn + 1), hipMemcpyHostToDevice, st));
+            const int32_t *soff = reinterpret_cast<const int32_t *>(hs + o_soff) + g0 + gi;  // (uploaded with the staging area, before the loop)
             HIP_TRY(hipMemsetAsync(c->d_lprog.p, 0, sizeof(int32_t) * static_cast<size_t>(gn) * n_jobs * max_strips, st));
             HIP_TRY(hipMemsetAsync(c->d_lticket.p, 0, 4, st));
-            sa.strip_off = reinterpret_cast<const int32_t *>(ds + o_soff);
+            sa.strip_off = reinterpret_cast<const int32_t *>(ds + o_soff) + g0 + gi;
             sa.progress = c->d_lprog.as<int32_t>();
             sa.ticket = c->d_lticket.as<unsigned>();
             const int64_t waves = static_cast<int64_t>(soff[gn]) * n_jobs;
@@ -499,7 +524,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.column_segments = c->opt_column_segments;
     pp.segment_warm_windows = c->opt_segment_warm;
     pp.allow_segments = !(c->flag & SFA_DTW) && !c->no_segments_once;
-    pp.lds_ckpt = (c->flag & SFA_DTW) ? 0 : static_cast<int>(c->opt_lds_ckpt);
+    pp.lds_ckpt = static_cast<int>(c->opt_lds_ckpt);
+    pp.std_dtw = (c->flag & SFA_DTW) != 0;
     std::vector<int32_t> long_reads;  // queries beyond the wave kernels' 2048 events: row strips, after the rest of the batch
     int64_t long_events = 0, long_max = 0;
     for (int32_t i = 0; i < n; ++i)
@@ -628,6 +654,9 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.prio_unit = static_cast<int32_t>(c->opt_prio_unit);
     if ((rc = c->d_started.reserve(64))) return rc;
     da.started = c->d_started.as<unsigned>();
+    da.err = c->d_badcount.as<unsigned>() + 4;
+    da.spin_limit = c->opt_spin_limit_ms * 100000;  // 100 MHz ticks
+    da.debug_drop_quad = static_cast<int32_t>(c->opt_debug_drop_quad);
 #ifdef SFA_TASK_TIMES
     if ((rc = c->d_times.reserve(24 * static_cast<size_t>(std::max(da.n_tasks, 1))))) return rc;
     da.task_times = c->d_times.as<unsigned long long>();
@@ -661,7 +690,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     if (da.prio_unit > 0) HIP_TRY(hipMemsetAsync(c->d_started.p, 0, 4, st));
     HIP_TRY(hipEventRecord(c->ev[0], st));
     // reads with a NaN / inf query value are skipped (the reference aborts on them, see sdtw_screen_kernel)
-    HIP_TRY(hipMemsetAsync(c->d_badcount.p, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(c->d_badcount.p, 0, 32, st));  // word 0: non-finite reads; words 4..6: error words of the in-launch waits
     hipLaunchKernelGGL(sfa::sdtw_screen_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_queries, da.q_off, n, c->d_bad.as<uint8_t>(),
                        c->d_badcount.as<unsigned>());
     KERNEL_TRY();
@@ -677,7 +706,10 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
             HIP_TRY(hipStreamWaitEvent(ls, c->lev[0], 0));
         }
         c->prof.fill_launches = 0;  // (counted per group of long reads inside)
-        if ((rc = align_long(c, d_queries, da.q_off, q_off, long_reads, long_max, d_out, ls))) return rc;
+        if ((rc = align_long(c, d_queries, da.q_off, q_off, long_reads, long_max, d_out, ls))) {
+            (void)hipStreamSynchronize(ls);  // nothing of a failed call may still be running when the caller reuses its buffers
+            return rc;
+        }
         long_launches = c->prof.fill_launches;
         if (c->opt_long_overlap) HIP_TRY(hipEventRecord(c->lev[1], ls));
     }
@@ -692,9 +724,9 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
                 KERNEL_TRY();
                 da.self = c->d_args.as<DpArgs>();
                 HIP_TRY(hipMemcpyAsync(c->d_args.p, &da, sizeof(DpArgs), hipMemcpyHostToDevice, st));  // (pageable source: staged before the call returns)
-                launch_fill_fused(plan.max_R, da, st, c->cu_count);
+                launch_fill_fused(plan.max_R, std_dtw, da, st, c->cu_count);
             } else {
-                launch_fill_lck(plan.max_R, da, st);
+                launch_fill_lck(plan.max_R, std_dtw, da, st);
             }
         } else if (plan.single_pass) {
             launch_fill<true>(plan.max_R, std_dtw, da, st);
@@ -723,7 +755,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         for (int i = 0; i < ta.n_cls; ++i) ta.cls[i].task_base = ta.cls[i].quad_base;  // one task per quad
         ta.n_tasks = n_quads;
         if (plan.lds_ckpt)
-            launch_trace_lck(plan.max_R, ta, c->d_tst.as<int32_t>(), st);
+            launch_trace_lck(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
         else
             launch_trace(plan.max_R, std_dtw, ta, c->d_tst.as<int32_t>(), st);
         KERNEL_TRY();
@@ -741,7 +773,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         HIP_TRY(hipEventRecord(c->ev[5], st));
         if (c->opt_long_overlap) HIP_TRY(hipStreamWaitEvent(st, c->lev[1], 0));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[4], st));
 
     c->prof.cells = (plan.query_events + long_events) * c->total_cols;
@@ -814,6 +846,16 @@ int resolve_profile(sfa_ctx *c) {
     c->prof.finalize_ms = t - a - d;
     c->prof.total_ms = t;
     c->prof_pending = false;
+    if (c->h_badcount.p) {  // a wave of the batch gave up waiting for another one (bounded_wait_ge): the rows are not to be used
+        const unsigned *e = c->h_badcount.as<unsigned>() + 4;
+        if (e[0] == sfa::kErrQuadWait)
+            return fail(SFA_EKERNEL, "fused launch: pass 2 of quad %u waited %lld ms for its fill tasks (%u of them had completed); rows of this batch are invalid",
+                        e[1], (long long)c->opt_spin_limit_ms, e[2]);
+        if (e[0] == sfa::kErrStripWait)
+            return fail(SFA_EKERNEL, "row strips: a strip waited %lld ms for column %u of the row above (column %u was published); rows of this batch are invalid",
+                        (long long)c->opt_spin_limit_ms, e[1], e[2]);
+        if (e[0]) return fail(SFA_EKERNEL, "device error word %u (%u, %u)", e[0], e[1], e[2]);
+    }
     return SFA_OK;
 }
 
@@ -1092,6 +1134,13 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "prio_unit") {
         if (value < 0 || value > (1 << 28)) return fail(SFA_EINVAL, "prio_unit must be 0 (off) .. 2^28");
         c->opt_prio_unit = value;
+    } else if (k == "spin_limit_ms") {
+        if (value < 1 || value > 3600000) return fail(SFA_EINVAL, "spin_limit_ms must be 1 .. 3 600 000");
+        c->opt_spin_limit_ms = value;
+    } else if (k == "debug_drop_quad") {
+        c->opt_debug_drop_quad = value;
+    } else if (k == "debug_drop_strip") {
+        c->opt_debug_drop_strip = value;
     } else if (k == "waves_per_simd") {
         if (value < 1 || value > 8) return fail(SFA_EINVAL, "waves_per_simd must be 1..8");
         c->opt_waves_per_simd = value;

@@ -62,6 +62,7 @@ struct PlanParams {
     int64_t segment_warm_windows = 4;  // windows (query lengths) a segment starts before its own first one
     bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory) and single pass
     int lds_ckpt = 0;               // 1: rolling checkpoints in LDS + sparse HBM checkpoints (sdtw_kernels.hpp, LdsCkpt) where the shapes allow and the batch size suits; 2: wherever the shapes allow
+    bool std_dtw = false;           // --dtw-std: with lds_ckpt the fill keeps NO LDS snapshots, only the sparse HBM store (the margin is not capped)
     bool skip_long = false;         // true: reads of more than kMaxQuery events are left out (the caller runs them in row strips, sdtw_strips.hpp)
 };
 
@@ -257,7 +258,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         const int64_t tasks = static_cast<int64_t>(n_quads) * p.n_chunks;
         if (pp.lds_ckpt < 2 && tasks > 4 * pp.n_sims && tasks <= 6 * pp.n_sims) p.lds_ckpt = false;
     }
-    if (p.lds_ckpt) p.trace_margin = std::min<int32_t>(p.trace_margin, 512 - maxq - 3);
+    if (p.lds_ckpt && !pp.std_dtw) p.trace_margin = std::min<int32_t>(p.trace_margin, 512 - maxq - 3);
     if (!pp.single_pass && n_quads > 0) {
         int shift = p.lds_ckpt ? 15 : 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length); sparse store: 32768
         if (pp.ckpt_interval > 0) {
