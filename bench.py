@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="also time sfa_align_batch with HOST query/result buffers (PCIe-inclusive; never `value`)")
     ap.add_argument("--opt", action="append", default=[], help="sfa_set_option key=value (tuning experiments)")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="after the timed region: every rank's rows as rank 0 received them == the rows that rank computed (checksums)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (raw BLOW5 -> PAF through the command line)")
     ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads in the generated BLOW5 files of the end-to-end leg")
     args = ap.parse_args()
@@ -164,8 +166,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
+    gathered = None
     if world > 1 or force_dist:  # final gather of the result rows (24 B/read/step) to rank 0, in read order
-        D.gather_rows(d_out, counts)
+        gathered = D.gather_rows(d_out, counts)
     torch.cuda.synchronize()
     if world > 1 or force_dist:
         dist.barrier()
@@ -175,6 +178,19 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    gather_verified = None
+    if args.check_gather:  # outside the timed region: rank r's slice on rank 0 against what rank r holds
+        import zlib
+        mine = torch.tensor([zlib.crc32(d_out.cpu().numpy().tobytes())], dtype=torch.int64, device=dev)
+        sums = [mine]
+        if world > 1 or force_dist:
+            sums = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(sums, mine)
+        if rank == 0:
+            got = gathered.view(np.uint8) if gathered is not None else d_out.cpu().numpy()
+            w = n * n_slots * S.RESULT_DTYPE.itemsize
+            gather_verified = [zlib.crc32(got[r * w:(r + 1) * w].tobytes()) for r in range(world)] == [int(t.item()) for t in sums]
 
     if rank != 0:
         al.close()
@@ -187,33 +203,63 @@ def main():
     launches_per_step = max(launches // max(args.steps, 1), 1)
     achieved = alg_bytes / kern_s / 1e9
     cells_per_s_kernel = cells / kern_s
-    ops_per_cell = 49 / 16  # counted from the shipped R=16 fill ISA: 49 VALU per 16-cell step
+    # VALU instructions per DP cell: counted from the steady-state loop of the kernel this workload runs, in the ISA of the
+    # library that is loaded (tools/isa_check.py; the Makefile leaves the figures next to the .so)
+    std = bool(flag & S.DTW)
+    isa_key = "std_fill" if std else ("fill32" if qlen > 1024 else "headline_fill")
+    ops_per_cell, ops_src = 49 / 16, "constant 49/16 (no ISA statistics next to the library)"
+    try:
+        isa = json.load(open(os.path.join(ROOT, "sigfish_amd", "lib", "libsigfish_amd.isa.json")))
+        ops_per_cell = float(isa[isa_key]["valu_per_cell"])
+        ops_src = f"sigfish_amd/lib/libsigfish_amd.isa.json: median steady-state loop of {isa_key} ({isa[isa_key]['kernel']})"
+    except (OSError, KeyError, TypeError, ValueError):
+        pass
     # HBM bytes per fill launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB -> bytes;
-    # MI355X_MICROARCH.md section HBM).  Counters cannot be collected inside this run, so the figure is only quoted when the
-    # newest profile under profiles/ was taken on THIS build of the library (profiles/<tag>_build_id.txt == sfa_build_id())
-    # on this workload; otherwise `traffic` is null and `traffic_source` says why.
-    traffic, traffic_src = None, None
+    # MI355X_MICROARCH.md section HBM).  Counters cannot be collected inside this run, so the figure is only quoted when a
+    # profile under profiles/ was taken on THIS build of the library, on this workload, batch size and options
+    # (profiles/<tag>_meta.json, written by tools/profile_round.sh); otherwise `traffic` is null and `traffic_source` says why.
+    traffic, traffic_src, issue = None, None, None
     import glob
-    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_build_id.txt")))
-    if not (args.workload == "ncov_r9_dna_q250" and n == 100_000 and not args.opt):
-        traffic_src = "not profiled: only the default workload and options have committed PMC passes"
-    elif not stamps:
-        traffic_src = "no profile under profiles/ carries a build id"
+
+    def natural(path):
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
+    metas = []
+    for mp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_meta.json")), key=natural):
+        try:
+            m = json.load(open(mp))
+        except ValueError:
+            continue
+        if m.get("workload") == args.workload and int(m.get("reads", -1)) == n and sorted(m.get("opts", [])) == sorted(args.opt):
+            metas.append((mp, m))
+    same = [(mp, m) for mp, m in metas if m.get("build_id") == S.build_id()]
+    if not metas:
+        traffic_src = f"not profiled: no profiles/*_meta.json for workload {args.workload}, {n} reads, options {sorted(args.opt)}"
+    elif not same:
+        mp, m = metas[-1]
+        traffic_src = f"stale: {os.path.basename(mp)} was taken on build {m.get('build_id')}, this library is build {S.build_id()}"
     else:
-        tag = os.path.basename(stamps[-1])[:-len("_build_id.txt")]
-        prof_build = open(stamps[-1]).read().strip()
+        mp, m = same[-1]
+        tag = os.path.basename(mp)[:-len("_meta.json")]
         pmc = os.path.join(ROOT, "profiles", tag + "_pmc_summary.csv")
-        if prof_build != S.build_id():
-            traffic_src = f"stale: profiles/{tag} was taken on build {prof_build}, this library is build {S.build_id()}"
-        elif os.path.exists(pmc):
-            vals = {}
+        if os.path.exists(pmc):
+            vals, durs = {}, {}
             for line in open(pmc).read().splitlines()[1:]:
-                kname, counter, _, mean, _ = line.rsplit(",", 4)
+                kname, counter, _, mean, dur = line.rsplit(",", 4)
                 if "sdtw_fill_kernel" in kname:
-                    vals[counter] = float(mean)
+                    vals[counter] = vals.get(counter, 0.0) + float(mean)
+                    durs[counter] = float(dur)
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                 traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-                traffic_src = f"profiles/{tag}_pmc_summary.csv (separate rocprofv3 --pmc passes of build {prof_build}, same workload)"
+                traffic_src = f"profiles/{tag}_pmc_summary.csv (separate rocprofv3 --pmc passes of build {m['build_id']}, same workload, batch size and options)"
+            if "SQ_INSTS_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+                # wave-instructions per cycle and SIMD over the profiled launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs), against
+                # what this opcode mix reaches in isolation (tools/valu_ceiling.hip: 0.455 -- v_min3 is half rate), and the clock
+                # the chip sustained meanwhile (power-limited; nominal 2.4 GHz)
+                cycles = vals["GRBM_GUI_ACTIVE"] / 8
+                rate = vals["SQ_INSTS_VALU"] / 1024 / cycles
+                issue = {"issue_rate": round(rate, 4), "issue_ceiling": 0.455, "attainable_frac": round(rate / 0.455, 4),
+                         "sustained_clock_ghz": round(cycles / (durs["GRBM_GUI_ACTIVE"] * 1e-3) / 1e9, 3),
+                         "source": f"profiles/{tag}_pmc_summary.csv (SQ_INSTS_VALU, GRBM_GUI_ACTIVE); ceiling: tools/valu_ceiling.hip"}
     out = {
         "metric": ("reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)" if args.workload == "ncov_r9_dna_q250"
                    else f"reads/s (sDTW alignment stage: {args.workload})"),
@@ -230,6 +276,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "library_build": S.build_id(),
+        **({"gather_verified": gather_verified} if gather_verified is not None else {}),
         "config": {"workload": args.workload, "reads_per_gpu": n, "query_events": qlen, "ref_kmers": int(ref.ref_lengths.sum()),
                    "strands": strands, "sharding": f"reads x{world}", "cells_per_read_full": qlen * cols},
         "dp_cells_per_s": round(cells * world * args.steps / elapsed, 1),
@@ -239,9 +286,13 @@ def main():
             "algorithmic_bytes_per_step": alg_bytes, "fill_launches_per_step": launches_per_step,
             "kernel_ms_per_step": round(kern_s * 1e3, 3),
             "trace_kernel_ms_per_step": round(sum(trace_ms) / max(len(trace_ms), 1), 3),
-            "valu": {"cells_per_s": round(cells_per_s_kernel, 1), "ops_per_cell": ops_per_cell,
+            # `frac` is against full-rate issue at the nominal clock, which this opcode mix cannot reach (v_min3 is half rate,
+            # the chip sustains ~2.1-2.2 GHz under this load); `attainable_frac` (when this build was profiled) is the measured
+            # issue rate against what the mix reaches in isolation -- the two must not be confused
+            "valu": {"cells_per_s": round(cells_per_s_kernel, 1), "ops_per_cell": round(ops_per_cell, 4), "ops_per_cell_source": ops_src,
                      "peak_cells_per_s": round(VALU_LANE_OPS / ops_per_cell, 1),
-                     "frac": round(cells_per_s_kernel * ops_per_cell / VALU_LANE_OPS, 4)},
+                     "frac": round(cells_per_s_kernel * ops_per_cell / VALU_LANE_OPS, 4),
+                     **(issue or {"attainable_frac": None})},
         },
     }
 

@@ -129,7 +129,8 @@ struct DpArgs {
     unsigned *g_best;
     int32_t *w_chunk;
     int32_t best_planes;   // planes per record (R of the largest class + 1)
-    int32_t coarse_every;  // every coarse_every-th LDS snapshot also goes to the HBM checkpoint store (ck_shift = 9 + log2 of it)
+    int32_t coarse_every;  // every coarse_every-th LDS snapshot also goes to the HBM checkpoint store (ck_shift = lck_shift + log2 of it)
+    int32_t lck_shift;     // LDS snapshots every 1 << lck_shift steps (9, 10 or 11 by the longest query of the batch)
     // fused launch (FUSED kernels): waves claim tickets; tickets < n_tasks are fill tasks, ticket n_tasks + q is pass 2 of quad q,
     // which waits until quad_done[q] == n_chunks.  Rows are written by the pass-2 waves (tables as FinalizeArgs).
     const struct DpArgs *self;  // this very block in device memory: what the pass-2 function of the fused launch reads (see there)
@@ -451,7 +452,8 @@ __device__ __forceinline__ constexpr int ck_planes() { return R + 2; }
 // What the record of a (quad, chunk) holds at the end is the snapshot for the chunk's best window whenever that window can
 // be the read's winner.  If the path turns out to start before the snapshot, pass 2 backs off to the sparse HBM
 // checkpoints (every coarse_every-th snapshot is also stored there, as before) and finally to the start of the strand.
-constexpr int kLdsCkShift = 9;
+constexpr int kLdsCkShift = 9;   // the SHORTEST interval between two LDS snapshots (queries up to 256 events); DpArgs::lck_shift is the batch's: the
+                                 // smallest of 512 / 1024 / 2048 steps that holds a window + the head start of pass 2 (see LdsCkpt::save)
 constexpr int kLdsCkPlanes = 17;  // R <= 16 costs + dprev
 struct LdsCkpt {
     float *buf;        // this lane's column of the wave's two buffers: buf[(j & 1) * kLdsCkPlanes * 64 + plane * 64]
@@ -476,7 +478,7 @@ struct LdsCkpt {
     // at the end of a window that began at step e_ws (steps since t_begin) and became the best of some read(s) of the quad:
     // improved = ballot of the lanes owning the last query row of those reads.  All 64 lanes are active here.
     template <int R, int L, bool WT = false>  // WT: write-through stores (the fused launch reads the record in the same launch)
-    __device__ __forceinline__ void save(unsigned long long improved, float wmin, int e_ws, int margin, int lq, int job) {
+    __device__ __forceinline__ void save(unsigned long long improved, float wmin, int e_ws, int margin, int lq, int job, int shift) {
         const int lane = threadIdx.x & 63;
         const int owner_lane = (lane & ~(L - 1)) + lq;
         const bool mine = (improved >> owner_lane) & 1;
@@ -485,10 +487,10 @@ struct LdsCkpt {
         if (mine && lane == owner_lane) old = atomicMin(g_best, wb);
         old = __shfl(old, owner_lane);
         if (!(mine && wb <= old)) return;
-        // the snapshot pass 2 would choose: index kk = floor((e_ws - margin - 3) / 512), taken at the first block boundary
-        // at or after kk * 512.  margin <= 512 - wl - 3, hence kk >= count - 1: still in its buffer.
+        // the snapshot pass 2 would choose: index kk = floor((e_ws - margin - 3) / S), S = 1 << shift, taken at the first block
+        // boundary at or after kk * S.  margin <= S - wl - 3, hence kk >= count - 1: still in its buffer.
         const int from = e_ws - margin - 3;
-        const int kk = from > 0 ? (from >> kLdsCkShift) : 0;
+        const int kk = from > 0 ? (from >> shift) : 0;
         if (kk > 0) {
             const float *b = buf + (kk & 1) * (kLdsCkPlanes * 64);
 #pragma unroll
@@ -537,17 +539,17 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     constexpr bool SNAP = LCK && !STD;
     if (SNAP) {
         lck->begin_job();
-        ck_next = 1 << kLdsCkShift;
+        ck_next = 1 << a.lck_shift;
     }
     auto maybe_checkpoint = [&]() {  // at a block boundary: snapshot the state BEFORE step t_begin + e
         if (SNAP) {
             if (e >= ck_next) {
                 lck->template snapshot<R>(cv, dprev, e);
-                ck_next += 1 << kLdsCkShift;
+                ck_next += 1 << a.lck_shift;
                 // every coarse_every-th one also goes to the sparse HBM store (what pass 2 backs off to), same format as below;
                 // write-through in the fused launch, whose pass 2 reads it in the same launch, possibly from another XCD (found by
                 // the fuzz campaign: a stale record there sent pass 2 off with a garbage step index)
-                if (T && (lck->count & (a.coarse_every - 1)) == 0 && (lck->count << kLdsCkShift) <= ck_last) {
+                if (T && (lck->count & (a.coarse_every - 1)) == 0 && (lck->count << a.lck_shift) <= ck_last) {
                     if (WT) {
 #pragma unroll
                         for (int r = 0; r < R; ++r) __hip_atomic_store(ckp + r * 64, static_cast<float>(cv[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -662,7 +664,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             const bool became_best = top.offer(wmin, (TRACK || CELL) ? wpos : col, wst, job);
             if (LCK) {
                 const unsigned long long improved = __ballot(became_best && owner);
-                if (improved) lck->template save<R, L, WT>(improved, wmin, col + e_main, a.trace_margin, lq, job);
+                if (improved) lck->template save<R, L, WT>(improved, wmin, col + e_main, a.trace_margin, lq, job, a.lck_shift);
             }
         } else {  // std_dtw: the single candidate C[n-1][m-1]
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);

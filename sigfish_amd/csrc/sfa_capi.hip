@@ -14,8 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <future>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sigfish_amd.h"
@@ -112,12 +116,72 @@ struct PinBuf {
     }
 };
 
+// One host thread per shard of a group context (sfa_init_devices), alive as long as the context: HIP's current device and
+// sfa_last_error are per thread, so every shard's calls are made from its own thread -- but not from a fresh one per call
+// (round 2: std::async per shard and call, i.e. a thread creation + the runtime's per-thread set-up inside every batch).
+class ShardWorker {
+  public:
+    ShardWorker() : th_([this] { loop(); }) {}
+    ~ShardWorker() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<int()> job) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = std::move(job);
+            state_ = 1;
+        }
+        cv_.notify_all();
+    }
+    std::pair<int, std::string> wait() {  // of the job posted last
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return state_ == 2; });
+        state_ = 0;
+        return {rc_, err_};
+    }
+
+  private:
+    void loop() {
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return quit_ || state_ == 1; });
+                if (quit_) return;
+                job = std::move(job_);
+            }
+            const int rc = job();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                rc_ = rc;
+                err_ = rc ? g_err : std::string();
+                state_ = 2;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    int state_ = 0;  // 0 idle, 1 posted, 2 done
+    bool quit_ = false;
+    int rc_ = 0;
+    std::string err_;
+    std::thread th_;  // last: started when everything else exists
+};
+
 }  // namespace
 
 struct sfa_ctx {
     // A GROUP context (sfa_init_devices) owns one ordinary context per listed device and nothing else: every batch is cut
     // into contiguous read ranges, one per shard, which run concurrently; rows land in the caller's array in input order.
     std::vector<sfa_ctx *> shards;
+    std::vector<std::unique_ptr<ShardWorker>> workers;  // [shards - 1]: shard r > 0 is driven from workers[r - 1], shard 0 from the caller
     std::vector<int32_t> shard_lo;  // [shards+1] read ranges of the batch submitted with sfa_submit_batch
 
     int device = 0;
@@ -641,7 +705,8 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     da.g_best = c->d_gbest.as<unsigned>();
     da.w_chunk = c->d_wchunk.as<int32_t>();
     da.best_planes = sfa::kLdsCkPlanes;
-    da.coarse_every = plan.lds_ckpt ? (1 << (plan.ck_shift - sfa::kLdsCkShift)) : 1;
+    da.lck_shift = plan.lck_shift;
+    da.coarse_every = (plan.lds_ckpt && plan.ck_shift >= plan.lck_shift) ? (1 << (plan.ck_shift - plan.lck_shift)) : 1;
     da.ticket = c->d_ticket.as<unsigned>();
     da.quad_done = c->d_quaddone.as<int32_t>();
     da.n_quads_total = n_quads;
@@ -992,21 +1057,16 @@ static void shard_ranges(int32_t n, size_t g, std::vector<int32_t> *lo) {
     for (size_t r = 0; r <= g; ++r) (*lo)[r] = static_cast<int32_t>(static_cast<int64_t>(n) * static_cast<int64_t>(r) / static_cast<int64_t>(g));
 }
 
-// run fn(shard index) for every shard, one host thread each (HIP's current device and sfa_last_error are per thread);
-// the first failure's code and message become the caller's
+// run fn(shard index) for every shard, each on the shard's own host thread (HIP's current device and sfa_last_error are
+// per thread), shard 0 on the caller's; the first failure's code and message become the caller's
 template <typename F>
 static int for_each_shard(sfa_ctx *g, F fn) {
     const size_t G = g->shards.size();
-    std::vector<std::future<std::pair<int, std::string>>> jobs;
-    for (size_t r = 1; r < G; ++r)
-        jobs.push_back(std::async(std::launch::async, [&fn, r] {
-            const int rc = fn(r);
-            return std::make_pair(rc, rc ? g_err : std::string());
-        }));
+    for (size_t r = 1; r < G; ++r) g->workers[r - 1]->post([&fn, r] { return fn(r); });
     int rc = fn(0);
     std::string msg = rc ? g_err : std::string();
-    for (auto &j : jobs) {
-        const auto res = j.get();
+    for (size_t r = 1; r < G; ++r) {  // (always all of them: fn and what it captures must outlive every worker's job)
+        const auto res = g->workers[r - 1]->wait();
         if (res.first && !rc) {
             rc = res.first;
             msg = res.second;
@@ -1041,6 +1101,7 @@ int sfa_init_devices(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, const
         }
         g->shards.push_back(c);
     }
+    for (int i = 1; i < n_devices; ++i) g->workers.emplace_back(new ShardWorker());
     *out = g;
     return SFA_OK;
 }
@@ -1048,6 +1109,7 @@ int sfa_init_devices(sfa_ctx_t **out, const sfa_ref_t *ref, uint32_t flag, const
 void sfa_destroy(sfa_ctx_t *c) {
     if (!c) return;
     if (!c->shards.empty()) {
+        c->workers.clear();  // joins the shard threads (none has a job: every entry point waits for its shards)
         for (sfa_ctx *sh : c->shards) sfa_destroy(sh);
         delete c;
         return;

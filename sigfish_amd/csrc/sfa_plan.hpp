@@ -73,6 +73,7 @@ struct PlanClass {
 
 struct BatchPlan {
     int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, widening = 1, ck_shift = 0, trace_margin = 0;
+    int32_t lck_shift = 9;  // with lds_ckpt: log2 of the interval between two LDS snapshots (9, 10, 11 for queries up to 256, 512, 1024 events)
     int32_t n_seg = 1, warm_windows = 4;  // column segments per job (sdtw_kernels.hpp, sweep_segment)
     bool single_pass = false;
     bool lds_ckpt = false;  // the fill keeps its snapshots in LDS; ck_shift is then the interval of the sparse HBM store
@@ -89,7 +90,7 @@ struct BatchPlan {
     std::vector<int32_t> s_qlen, s_count, s_quad_start, s_fill_pos;
     std::vector<int8_t> s_per_shift;
     void reset() {  // scalars back to their defaults; vectors keep their capacity
-        n_quads = 0; n_chunks = 1; max_R = 4; max_lanes = 16; widening = 1; ck_shift = 0; trace_margin = 0;
+        n_quads = 0; n_chunks = 1; max_R = 4; max_lanes = 16; widening = 1; ck_shift = 0; trace_margin = 0; lck_shift = 9;
         n_seg = 1; warm_windows = 4;
         single_pass = false;
         lds_ckpt = false;
@@ -142,11 +143,25 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // classes in task order (long first); inside a class by descending length.  layout(w) fills the plan for lane
     // widening w and returns the number of quads (waves' worth of reads).
     quad_start.assign(maxq + 2, -1);
+    // Queries of 257 .. 1024 events on the LDS-checkpoint route: their base shapes hold 32 rows per lane (16 or 32 lanes per
+    // read), whose snapshots (33 planes) do not fit LDS twice at four waves per SIMD.  The same queries fit 16 rows x 32 / 64
+    // lanes (two reads / one read per wave) -- the shapes of "lane widening" 2 --, which run the 16-row kernels: rolling
+    // snapshots in LDS (every 1024 / 2048 steps instead of 512, so that a window and the head start of pass 2 fit one interval),
+    // pass 2 by ticket in the same launch, and the 3.06-instruction cell of the headline kernel instead of the 32-row step
+    // with its window-cell bookkeeping.  Not for batches that also hold queries beyond 1024 events: those need 32 rows x 64 lanes
+    // and the 32-row kernels anyway.
+    // Measured (profiles/r03_logs/ab_q500_q1000_q700_*.jsonl, ms per step of the same cell count, this route / the 32-row kernels
+    // with every snapshot in HBM and pass 2 as its own launch): q = 500 89.6 / 87.9, q = 700 131.2 / 130.5, q = 1000 95.9 / 94.4 --
+    // the 32-row step is no slower per cell (3.05 VALU per cell against 3.09) and its pass 1 names the winning CELL, so its pass 2
+    // is shorter (4.5 against ~6 ms at q = 500); what this route saves is the 12.6 GB of snapshot stores per launch and three
+    // launches, not time.  It is therefore taken only on request (lds_ckpt = 2); lds_ckpt = 1 keeps the 32-row kernels.
+    const bool r32_as_r16 = pp.lds_ckpt >= 2 && !pp.single_pass && pp.ckpt_interval == 0 && maxq > 256 && maxq <= 1024;
+    auto class_widening = [&](int ci, int w) { return (r32_as_r16 && (ci == 1 || ci == 2)) ? std::max(w, 2) : w; };
     auto layout = [&](int w) {
         p.classes.clear();
         int32_t n_quads = 0;
         for (int ci = 0; ci < 6; ++ci) {
-            const ClassShape sh = widened(ci, w);
+            const ClassShape sh = widened(ci, class_widening(ci, w));
             PlanClass cl;
             cl.R = sh.R;
             cl.lanes = sh.lanes;
@@ -201,7 +216,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     per_shift.assign(maxq + 2, 0);  // log2(reads per wave) of every query length that occurs (4, 2 or 1 reads)
     for (int l = 1; l <= maxq; ++l)
         if (count[l]) {
-            const int per = 64 / widened(class_for(l), w).lanes;
+            const int per = 64 / widened(class_for(l), class_widening(class_for(l), w)).lanes;
             per_shift[l] = per == 4 ? 2 : (per == 2 ? 1 : 0);
         }
     for (int32_t i = 0; i < n; ++i) {
@@ -215,7 +230,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     }
     for (int l = 1; l <= maxq; ++l)
         if (count[l]) {
-            const int per = 64 / widened(class_for(l), w).lanes;
+            const int per = 64 / widened(class_for(l), class_widening(class_for(l), w)).lanes;
             for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + per - 1) / per; ++qd) p.quad_qlen[qd] = l;
         }
 
@@ -250,15 +265,16 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + p.max_lanes);
     // LDS checkpoints: every shape of the batch must hold its state in 17 planes (R <= 16), one sweep per (quad, job); the
     // margin is capped so that the snapshot pass 2 wants for a window is one of the last two (LdsCkpt::save):
-    // 512 >= window length + margin + 3
-    p.lds_ckpt = pp.lds_ckpt && !pp.single_pass && pp.ckpt_interval == 0 && p.max_R <= 16 && p.n_seg == 1 && n_quads > 0 && maxq <= 256;
+    // interval (512 / 1024 / 2048 by the longest query) >= window length + margin + 3
+    p.lds_ckpt = pp.lds_ckpt && !pp.single_pass && pp.ckpt_interval == 0 && p.max_R <= 16 && p.n_seg == 1 && n_quads > 0 && maxq <= 1024;
+    p.lck_shift = maxq <= 256 ? 9 : (maxq <= 512 ? 10 : 11);
     {   // the LDS buffers cap the fill at four waves per SIMD instead of six: a batch whose tasks are all resident at six
         // but not at four would need a second round (measured: 8 192 reads 7.35 -> 7.65 ms); everything else gains
         // (16 384 reads 13.7 -> 13.4 ms, 100 000 reads 74.6 -> 73.5 ms)
         const int64_t tasks = static_cast<int64_t>(n_quads) * p.n_chunks;
         if (pp.lds_ckpt < 2 && tasks > 4 * pp.n_sims && tasks <= 6 * pp.n_sims) p.lds_ckpt = false;
     }
-    if (p.lds_ckpt && !pp.std_dtw) p.trace_margin = std::min<int32_t>(p.trace_margin, 512 - maxq - 3);
+    if (p.lds_ckpt && !pp.std_dtw) p.trace_margin = std::min<int32_t>(p.trace_margin, (1 << p.lck_shift) - maxq - 3);
     if (!pp.single_pass && n_quads > 0) {
         int shift = p.lds_ckpt ? 15 : 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length); sparse store: 32768
         if (pp.ckpt_interval > 0) {

@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-from tests.util import ROOT
+from tests.util import ROOT, visible_gpus
 
 pytestmark = pytest.mark.gpu
 
@@ -40,3 +40,23 @@ def test_bench_json_line():
     assert e2e["reads"] == 2000 and e2e["unit"] == "reads/s"
     assert d["library_build"] and d["rccl_world_size"] == 1
     assert d["roofline"]["traffic"] is None  # a 3000-read batch was never profiled: no stale counters are quoted
+
+
+def test_bench_over_rccl_on_every_gpu_the_box_has():
+    """`bench.py --gpus G` over RCCL: on a box with G > 1 GPUs with min(G, 4) ranks (it starts them itself), on a one-GPU box as
+    a one-rank rehearsal of the same path (SFA_DIST_FORCE=1: broadcast of the reference model, gather of the rows).  The
+    line must say how many ranks really existed, and rank 0 must have received exactly the rows every rank computed."""
+    g = min(visible_gpus(), 4)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if g <= 1:
+        g = 1
+        env["SFA_DIST_FORCE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(g), "--steps", "2", "--warmup", "1", "--reads", "20000",
+                        "--no-cpu-baseline", "--no-e2e", "--check-gather"], capture_output=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == g and d["rccl_world_size"] == g and d["config"]["sharding"] == f"reads x{g}"
+    assert d["gather_verified"] is True
+    assert d["scaling"] == "weak" and d["value"] > 0

@@ -66,9 +66,18 @@ def test_cli_small_batches_keep_order(models, k, extra):
     assert r.stdout.decode() == c["out_text"]
 
 
-@pytest.mark.parametrize("extra", [["--device", "0,0"], ["--device", "0,0", "--streams", "1"], ["--streams", "3"]])
+def _device_args():
+    from tests.util import distinct_device_list
+    lists = [["--device", "0,0"], ["--device", "0,0", "--streams", "1"], ["--streams", "3"]]
+    devs = distinct_device_list()
+    if devs:  # a box with several GPUs: every one of them, without a code change
+        lists += [["--device", ",".join(map(str, devs))], ["--device", ",".join(map(str, devs)), "--streams", "1"]]
+    return lists
+
+
+@pytest.mark.parametrize("extra", _device_args(), ids=lambda e: "_".join(e).replace("--", "").replace(",", ""))
 def test_cli_device_list_and_streams(models, extra):
-    """Batches dealt to several contexts / devices in turn (the one GPU of the test box listed twice) come out in order."""
+    """Batches dealt to several contexts / devices in turn (one GPU listed twice; every GPU of a multi-GPU box) come out in order."""
     c = load_case("rna_default")
     cmd = [BIN, "dtw", "--kmer-model", models[5], "--verbose", "0", "-K", "1", "--rna", *extra, c["fasta"], c["blow5"]]
     r = subprocess.run(cmd, capture_output=True, timeout=300)

@@ -83,3 +83,30 @@ def write_blow5(path, reads, attrs=(("experiment_type", "genomic_dna"), ("sequen
                 payload = zlib.compress(payload, 6)
             out.write(struct.pack("<Q", len(payload)) + payload)
         out.write(b"5WOLB")
+
+
+def visible_gpus():
+    """GPUs this process can see, without initialising any of them (torch.cuda.device_count() does not, on this image)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def device_lists():
+    """Device lists for the sharding tests.  One physical GPU listed two and three times always (several shards on one GPU,
+    each with its own stream, scratch and host thread); wherever the box has MORE than one GPU the lists widen by themselves:
+    every device once, every device in reverse order, and the first two -- so the first multi-GPU box that runs the suite
+    exercises hipMemcpyPeer between distinct devices and one host thread per device without a code change."""
+    lists = [[0, 0], [0, 0, 0]]
+    g = visible_gpus()
+    if g > 1:
+        lists += [list(range(g)), list(range(g - 1, -1, -1)), [0, 1]]
+    return lists
+
+
+def distinct_device_list():
+    """[0 .. G-1] when the box has G > 1 GPUs, else None (tests that only make sense across devices skip)."""
+    g = visible_gpus()
+    return list(range(g)) if g > 1 else None

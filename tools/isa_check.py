@@ -283,8 +283,8 @@ def hot_path_mix(ins_list, s, e, succ):
     return mix
 
 
-def fill_loop_stats(funcs, pattern):
-    """steady-state loops (>= 64 cells per trip) of the kernels whose symbol matches `pattern`: VALU per cell"""
+def fill_loop_stats(funcs, pattern, min_cells=64):
+    """steady-state loops (>= min_cells cells per trip) of the kernels whose symbol matches `pattern`: VALU per cell"""
     best = None
     for name, ins in funcs.items():
         if not re.search(pattern, name):
@@ -293,7 +293,7 @@ def fill_loop_stats(funcs, pattern):
         per = []
         for s, e in loops(ins):
             m = hot_path_mix(ins, s, e, succ)
-            if m and m["cells"] >= 64:
+            if m and m["cells"] >= min_cells:
                 per.append(m)
         if not per:
             continue
@@ -317,8 +317,11 @@ def main(argv):
             so = a
     funcs = disassemble(so)
     bad, seen = protocol_violations(funcs)
+    # <MAXR, TRACK, STD, SEG, LCK, FUSED>: the kernels bench.py's workloads run at full batch size
     stats = {"kernels_checked": seen, "violations": bad,
-             "headline_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb0ELb1ELb1E")}
+             "headline_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb0ELb1ELb1E"),
+             "std_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb1ELb0ELb1ELb1E"),
+             "fill32": fill_loop_stats(funcs, r"sdtw_fill_kernelILi32ELb0ELb0ELb0ELb0ELb0E", min_cells=128)}  # (its 32-row loops only)
     text = json.dumps(stats, indent=1)
     if out:
         with open(out, "w") as f:

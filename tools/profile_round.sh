@@ -18,4 +18,4 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY
 pass grbm GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
-python3 $ROOT/tools/summarise_profiles.py $OUT $TAG
+python3 $ROOT/tools/summarise_profiles.py $OUT $TAG "$@"

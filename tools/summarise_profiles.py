@@ -15,7 +15,7 @@ def short(name):
     return name.split("(")[0].strip()
 
 
-def main(d, tag):
+def main(d, tag, bench_args=()):
     ks = glob.glob(os.path.join(d, "kt", "**", "*_kernel_stats.csv"), recursive=True)
     if ks:
         shutil.copyfile(ks[0], os.path.join(d, f"{tag}_kernel_stats.csv"))
@@ -44,8 +44,21 @@ def main(d, tag):
                 rows.append((k, c, len(keep), sum(vals) / len(vals), sum(durs) / len(durs)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import sigfish_amd
-    with open(os.path.join(d, f"{tag}_build_id.txt"), "w") as f:  # bench.py quotes these counters only for this build
-        f.write(sigfish_amd.build_id() + "\n")
+    # bench.py quotes these counters only for this build, workload, batch size and options
+    import argparse
+    import json
+    import re
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="ncov_r9_dna_q250")
+    ap.add_argument("--reads", type=int, default=None)
+    ap.add_argument("--opt", action="append", default=[])
+    a, _ = ap.parse_known_args(list(bench_args))
+    qlen = int(re.search(r"_q(\d+)$", a.workload).group(1))
+    reads = a.reads if a.reads is not None else 100_000 * 250 // qlen
+    with open(os.path.join(d, f"{tag}_meta.json"), "w") as f:
+        json.dump({"build_id": sigfish_amd.build_id(), "workload": a.workload, "reads": reads, "opts": a.opt,
+                   "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e " + " ".join(bench_args)}, f)
+        f.write("\n")
     with open(os.path.join(d, f"{tag}_pmc_summary.csv"), "w") as f:
         f.write("kernel,counter,dispatches,mean_value_per_dispatch,mean_duration_ms_in_that_pass\n")
         for k, c, n, v, t in rows:
@@ -54,4 +67,4 @@ def main(d, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])
