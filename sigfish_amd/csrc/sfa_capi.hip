@@ -188,11 +188,13 @@ struct sfa_ctx {
     uint32_t flag = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_long = nullptr;       // the row strips of long queries run beside the wave kernels of the same batch
+    hipStream_t stream_pre = nullptr;        // SFA_RESERVED_CUS=N: record decoding + event detection on N CUs of their own (CU-masked stream), alignment on the rest
     hipEvent_t lev[2] = {nullptr, nullptr};  // inputs of the batch ready on `stream` / strips done on `stream_long`
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end, row strips start
     hipEvent_t eev[4] = {nullptr, nullptr, nullptr, nullptr};  // sfa_align_raw: event detection start/end, normalisation start/end
     bool eev_pending = false;
     int cu_count = 256;
+    int pre_cus = 0;  // CUs of stream_pre (0: no partition, the pre-alignment stages see the whole device)
 
     // tunables (sfa_set_option)
     int64_t opt_single_pass = 0;             // 1: one fill with start tracking everywhere (first-round design)
@@ -1014,8 +1016,26 @@ static int create_context(sfa_ctx **out, const HostRef &h, uint32_t flag, int de
         sfa_destroy(c);
         return rc;
     };
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
-    if (hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
+    // CU partition (experiment, profiles/r03_logs/cu_partition_*.log): the inflate kernel (57 KB of LDS per wave) and the
+    // LDS-checkpoint fill (152 of 160 KB per CU) cannot share a CU, so with two contexts in flight the decoder of one batch queues
+    // behind the fill of the other.  SFA_RESERVED_CUS=N gives the pre-alignment stages (sfa_align_blow5 / sfa_align_raw up to the
+    // event counts) a stream masked to the LAST N CUs and the alignment streams the others.
+    int reserved = 0;
+    if (const char *e = getenv("SFA_RESERVED_CUS")) reserved = atoi(e);
+    if (reserved > 0 && reserved < c->cu_count) {
+        const int words = (c->cu_count + 31) / 32;
+        std::vector<uint32_t> main_mask(words, 0), pre_mask(words, 0);
+        for (int i = 0; i < c->cu_count; ++i) (i < c->cu_count - reserved ? main_mask : pre_mask)[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&c->stream, words, main_mask.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&c->stream_long, words, main_mask.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&c->stream_pre, words, pre_mask.data()) != hipSuccess)
+            return bail(fail(SFA_ENODEV, "hipExtStreamCreateWithCUMask failed (SFA_RESERVED_CUS=%d of %d CUs)", reserved, c->cu_count));
+        c->cu_count -= reserved;  // what the planner and the launch sizes see
+        c->pre_cus = reserved;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
+        if (hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
+    }
     for (auto &e : c->lev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     for (auto &e : c->ev)
@@ -1137,6 +1157,7 @@ void sfa_destroy(sfa_ctx_t *c) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->lev)
         if (e) (void)hipEventDestroy(e);
+    if (c->stream_pre) (void)hipStreamDestroy(c->stream_pre);
     if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1380,10 +1401,11 @@ static int align_raw_impl(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_o
         (rc = c->e_nev.reserve(4 * (size_t)n)) || (rc = c->e_qstart.reserve(8 * (size_t)n)) || (rc = c->e_qoff.reserve(8 * (size_t)(n + 1))) ||
         (rc = c->e_flag.reserve(4 * (size_t)n)) || (rc = c->e_pflag.reserve(4 * (size_t)n)) || (rc = c->e_b0.reserve(4 * (size_t)n)) || (rc = c->e_b1.reserve(4 * (size_t)n)) || (rc = c->e_b2.reserve(4 * (size_t)n)))
         return rc;
-    if (raw) HIP_TRY(hipMemcpyAsync(c->e_raw.p, raw, 2 * (size_t)total, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->e_scale.p, scale.data(), 8 * (size_t)n, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->e_evoff.p, ev_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, st));
+    hipStream_t sp = c->stream_pre ? c->stream_pre : st;  // (the section ends with a host wait on it: no cross-stream event needed)
+    if (raw) HIP_TRY(hipMemcpyAsync(c->e_raw.p, raw, 2 * (size_t)total, hipMemcpyHostToDevice, sp));
+    HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, sp));
+    HIP_TRY(hipMemcpyAsync(c->e_scale.p, scale.data(), 8 * (size_t)n, hipMemcpyHostToDevice, sp));
+    HIP_TRY(hipMemcpyAsync(c->e_evoff.p, ev_off.data(), 8 * (size_t)(n + 1), hipMemcpyHostToDevice, sp));
 
     sfa::EvArgs ea{};
     ea.raw = c->e_raw.as<int16_t>();
@@ -1413,19 +1435,19 @@ static int align_raw_impl(sfa_ctx_t *c, const int16_t *raw, const int64_t *raw_o
     // measured: 76 us against 1.5 ms for a 512-read batch, 2.1 ms against 1.3 ms for 16 Ki reads (it does ~1.3x the work of
     // the sequential walk, in 64x more waves): used while the batch cannot fill the chip with one read per lane pair
     ea.use_peak_flags = (c->opt_ev_parallel_peaks && n <= 8192) ? 1 : 0;
-    HIP_TRY(hipEventRecord(c->eev[0], st));
-    if (ea.use_flags) hipLaunchKernelGGL(sfa::ev_prefix_par_kernel, dim3(n), dim3(64), 0, st, ea);  // flags what it cannot do exactly
-    hipLaunchKernelGGL(sfa::ev_prefix_kernel, lane_grid, lane_block, 0, st, ea);
-    hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, st, ea);
-    if (ea.use_peak_flags) hipLaunchKernelGGL(sfa::ev_peaks_spec_kernel, dim3(n), dim3(64), 0, st, ea);  // wave per read, flags what it cannot certify
-    hipLaunchKernelGGL(sfa::ev_peaks_kernel, dim3((n + 31) / 32), dim3(64), 0, st, ea);  // two lanes per read (all reads, or the flagged ones)
-    hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, st, ea);
+    HIP_TRY(hipEventRecord(c->eev[0], sp));
+    if (ea.use_flags) hipLaunchKernelGGL(sfa::ev_prefix_par_kernel, dim3(n), dim3(64), 0, sp, ea);  // flags what it cannot do exactly
+    hipLaunchKernelGGL(sfa::ev_prefix_kernel, lane_grid, lane_block, 0, sp, ea);
+    hipLaunchKernelGGL(sfa::ev_tstat_kernel, dim3(n), dim3(256), 0, sp, ea);
+    if (ea.use_peak_flags) hipLaunchKernelGGL(sfa::ev_peaks_spec_kernel, dim3(n), dim3(64), 0, sp, ea);  // wave per read, flags what it cannot certify
+    hipLaunchKernelGGL(sfa::ev_peaks_kernel, dim3((n + 31) / 32), dim3(64), 0, sp, ea);  // two lanes per read (all reads, or the flagged ones)
+    hipLaunchKernelGGL(sfa::ev_stats_kernel, dim3(n), dim3(256), 0, sp, ea);
     KERNEL_TRY();
-    HIP_TRY(hipEventRecord(c->eev[1], st));
+    HIP_TRY(hipEventRecord(c->eev[1], sp));
     if ((rc = c->h_small.reserve(16 * (size_t)n))) return rc;  // page-locked: event counts, then the three raw-coordinate columns
     int32_t *nev = c->h_small.as<int32_t>();
-    HIP_TRY(hipMemcpyAsync(nev, c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(nev, c->e_nev.p, 4 * (size_t)n, hipMemcpyDeviceToHost, sp));
+    HIP_TRY(hipStreamSynchronize(sp));
 
     // query windows on the host (normalise_single, src/sigfish.c:433-480); the arithmetic part runs on the device
     std::vector<int64_t> qstart(n), q_off(n + 1);
@@ -1560,16 +1582,17 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
         (rc = c->b_len.reserve(4 * static_cast<size_t>(n))) || (rc = c->b_bad.reserve(4 * static_cast<size_t>(n))))
         return rc;
     if (record_zlib && ((rc = c->b_out.reserve(static_cast<size_t>(slot[n]) + 64)) || (rc = c->b_outoff.reserve(8 * static_cast<size_t>(n + 1))))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->b_in.p, records, static_cast<size_t>(in_bytes), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(c->b_inoff.p, rec_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(c->b_bad.p, 0, 4 * static_cast<size_t>(n), st));
-    HIP_TRY(hipEventRecord(c->bev[0], st));
+    hipStream_t sp = c->stream_pre ? c->stream_pre : st;  // (every section below ends with a host wait on it)
+    HIP_TRY(hipMemcpyAsync(c->b_in.p, records, static_cast<size_t>(in_bytes), hipMemcpyHostToDevice, sp));
+    HIP_TRY(hipMemcpyAsync(c->b_inoff.p, rec_off, 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, sp));
+    HIP_TRY(hipMemsetAsync(c->b_bad.p, 0, 4 * static_cast<size_t>(n), sp));
+    HIP_TRY(hipEventRecord(c->bev[0], sp));
     sfa::FieldsArgs fa{};
     if (record_zlib) {
-        HIP_TRY(hipMemcpyAsync(c->b_outoff.p, slot.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->b_outoff.p, slot.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, sp));
         sfa::InflateArgs ia{c->b_in.as<uint8_t>(), c->b_inoff.as<int64_t>(), c->b_out.as<uint8_t>(), c->b_outoff.as<int64_t>(), c->b_len.as<int32_t>(), n};
-        const int lanes = inflate_lanes(n, c->cu_count);
-        hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + lanes - 1) / lanes), dim3(64), sizeof(sfa::InflateLds) * lanes, st, ia, lanes);
+        const int lanes = inflate_lanes(n, c->pre_cus ? c->pre_cus : c->cu_count);
+        hipLaunchKernelGGL(sfa::blow5_inflate_kernel, dim3((n + lanes - 1) / lanes), dim3(64), sizeof(sfa::InflateLds) * lanes, sp, ia, lanes);
         KERNEL_TRY();
         fa.payload = c->b_out.as<uint8_t>();
         fa.payload_off = c->b_outoff.as<int64_t>();
@@ -1582,11 +1605,11 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
     fa.head = c->b_head.as<uint8_t>();
     fa.signal_svb = signal_svb ? 1 : 0;
     fa.n = n;
-    hipLaunchKernelGGL(sfa::blow5_fields_kernel, dim3((n + 63) / 64), dim3(64), 0, st, fa);
+    hipLaunchKernelGGL(sfa::blow5_fields_kernel, dim3((n + 63) / 64), dim3(64), 0, sp, fa);
     KERNEL_TRY();
     uint8_t *hh = c->h_head.as<uint8_t>();
-    HIP_TRY(hipMemcpyAsync(hh, c->b_head.p, static_cast<size_t>(n) * sfa::kBlow5HeadBytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpyAsync(hh, c->b_head.p, static_cast<size_t>(n) * sfa::kBlow5HeadBytes, hipMemcpyDeviceToHost, sp));
+    HIP_TRY(hipStreamSynchronize(sp));
     // the fields of every record; anything the device declined sends the whole batch to the host reader
     std::vector<int64_t> raw_off(n + 1);
     std::vector<double> scaling(3 * static_cast<size_t>(n));
@@ -1621,15 +1644,15 @@ int sfa_align_blow5(sfa_ctx_t *c, const uint8_t *records, const int64_t *rec_off
     if (!fallback) {
         const int64_t total = raw_off[n];
         if ((rc = c->e_raw.reserve(2 * static_cast<size_t>(std::max<int64_t>(total, 1)))) || (rc = c->e_rawoff.reserve(8 * static_cast<size_t>(n + 1)))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->e_rawoff.p, raw_off.data(), 8 * static_cast<size_t>(n + 1), hipMemcpyHostToDevice, sp));
         sfa::SvbArgs sa{fa.payload, fa.payload_off, c->b_head.as<uint8_t>(), c->e_rawoff.as<int64_t>(), c->e_raw.as<int16_t>(), c->b_bad.as<int32_t>(),
                         signal_svb ? 1 : 0, n};
-        hipLaunchKernelGGL(sfa::blow5_svb_kernel, dim3((n + 3) / 4), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(sfa::blow5_svb_kernel, dim3((n + 3) / 4), dim3(256), 0, sp, sa);
         KERNEL_TRY();
         int32_t *bad = reinterpret_cast<int32_t *>(hh + static_cast<size_t>(n) * sfa::kBlow5HeadBytes);
-        HIP_TRY(hipMemcpyAsync(bad, c->b_bad.p, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(c->bev[1], st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(bad, c->b_bad.p, 4 * static_cast<size_t>(n), hipMemcpyDeviceToHost, sp));
+        HIP_TRY(hipEventRecord(c->bev[1], sp));
+        HIP_TRY(hipStreamSynchronize(sp));
         for (int32_t i = 0; i < n && !fallback; ++i)
             if (bad[i] != 0) {
                 (void)fail(SFA_OK, "sfa_align_blow5: signal of record %d is shorter than its keys say: host reader takes the batch", i);

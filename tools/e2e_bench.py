@@ -24,9 +24,35 @@ BIN = os.path.join(ROOT, "sigfish_amd", "bin", "sigfish-amd")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def _scratch_dir(need_bytes):
+    """Where the generated files go: memory-backed /dev/shm when it has room (the leg measures the pipeline, not the box's
+    disk), else the ordinary temporary directory."""
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize > 2 * need_bytes:
+            return tempfile.mkdtemp(prefix="sfa_e2e_", dir="/dev/shm"), "/dev/shm (memory-backed)"
+    except OSError:
+        pass
+    return tempfile.mkdtemp(prefix="sfa_e2e_"), tempfile.gettempdir()
+
+
+def _warm(path):
+    """The file was written seconds ago: flush it, then read it once, so that no timed run pays the write-back of dirty pages or
+    a cold page cache (round 2's driver run recorded 0.15 M reads/s for the FIRST configuration on a 3.8 GB file and 0.39-0.49 M
+    for every later one: that first figure was the box's disk, not the pipeline)."""
+    os.sync()
+    with open(path, "rb", buffering=0) as f:
+        while f.read(1 << 24):
+            pass
+
+
 def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
-    d = keep_dir or tempfile.mkdtemp(prefix="sfa_e2e_")
-    out = {"unit": "reads/s", "reads": 0, "host_threads": threads,
+    where = "given directory"
+    d = keep_dir
+    if d is None:
+        d, where = _scratch_dir(reads * 10_000)  # ~9.6 KB per read uncompressed
+    out = {"unit": "reads/s", "reads": 0, "host_threads": threads, "files_in": where,
+           "page_cache": "warm: every generated file is synced and read once before its first timed run",
            "what": "raw BLOW5 -> PAF through `sigfish-amd dtw` (process start to exit), reference's DNA fixture replicated, nCoV reference"}
     try:
         lv = np.fromfile(os.path.join(GOLD, "models", "syn6.f32"), np.float32)
@@ -42,6 +68,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
                             "--copies", str(copies), "--jobs", str(min(threads, 16)), *flags], check=True, capture_output=True)
             out[kind + "_file_MB"] = round(os.path.getsize(path) / 1e6, 1)
+            _warm(path)
             for k in ks:
                 paf = os.path.join(d, "out.paf")
                 t0 = time.perf_counter()
