@@ -223,10 +223,12 @@ constexpr int kXchWordsPerWave = 128;
 struct Exchange {
     float *wf, *rf;  // this lane's store / load slot (bottom cost)
     int *wi, *ri;    // same for the bottom start column, TRACK only
-    __device__ __forceinline__ void init(float *lds_f, int *lds_i, int wave_in_block, int slot, int g, int L) {
+    // g0: the lane that holds query row 0 of this read (0 unless the read shares its wave with longer ones, see MixedQuad): that
+    // lane loads the boundary word instead of its neighbour's value, so the lanes in front of it feed nothing
+    __device__ __forceinline__ void init(float *lds_f, int *lds_i, int wave_in_block, int slot, int g, int L, int g0 = 0) {
         const int base = wave_in_block * kXchWordsPerWave;
         const int w = base + (g < L - 1 ? slot * L + g + 1 : 64 + L * slot);
-        const int r = base + slot * L + g;
+        const int r = base + slot * L + (g == g0 ? 0 : g);
         wf = lds_f + w;
         rf = lds_f + r;
         wi = lds_i + w;
@@ -294,6 +296,34 @@ struct Top2 {
         if (TRACK) st = top ? start : st;
         job = top ? j : job;
         return top;
+    }
+    // the same for the lanes where `on` holds (reads of a wave whose windows end at different columns)
+    __device__ __forceinline__ bool offer_if(bool on, float sc, int32_t pos, int32_t start, int32_t j) {
+        const bool top = on && !(sc > best);
+        const bool sec = on && !(sc > second);
+        second = top ? best : (sec ? sc : second);
+        best = top ? sc : best;
+        end = top ? pos : end;
+        if (TRACK) st = top ? start : st;
+        job = top ? j : job;
+        return top;
+    }
+};
+
+// MIXED QUADS.  The reads of a wave used to have ONE query length (the planner grouped by length), so a ragged batch -- a few
+// hundred distinct lengths -- left most of the short reads' waves a quarter or half full.  Reads of different lengths can share
+// a wave when they are laid out from the END: every read's LAST query row sits in the same lane and register (lq, rq: those of
+// the longest read of the wave, whose length is quad_qlen), a shorter read simply begins in a later lane g0 -- at register 0 of
+// that lane, which is why the lengths of a wave agree modulo R (the planner's rule).  Lane g0 takes the boundary of query row 0
+// (Exchange::init), the lanes in front of it compute cells nobody reads.  What differs per read is the WINDOW length of the
+// last-row scan (src/sigfish.c:891-901: windows of qlen columns), handled in sweep_job; nothing in the step itself.
+struct MixedQuad {
+    int myq;  // query length of this lane's read (the wave's longest for an empty slot)
+    int g0;   // first lane of the read's L-lane row that holds query rows
+    template <int R>
+    __device__ __forceinline__ void init(const DpArgs &a, int read, int qmax) {
+        myq = read >= 0 ? static_cast<int>(a.q_off[read + 1] - a.q_off[read]) : qmax;
+        g0 = (qmax - myq) / R;
     }
 };
 
@@ -416,13 +446,13 @@ __device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev,
 }
 
 template <int R>
-__device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, int read, int qlen, int g) {
+__device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, int read, int qlen, int g, int g0 = 0) {
     const float *q = a.queries + a.q_off[read >= 0 ? read : 0];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int i = g * R + r;
+        const int i = (g - g0) * R + r;  // (qlen: this read's own length; rows in front of lane g0 and past the end are zeros)
         const int src = a.rev_query ? (qlen - 1 - i) : i;
-        x[r] = (read >= 0 && i < qlen) ? q[src] : 0.0f;
+        x[r] = (read >= 0 && i >= 0 && i < qlen) ? q[src] : 0.0f;
     }
 }
 
@@ -475,8 +505,9 @@ struct LdsCkpt {
         else
             e0 = e;
     }
-    // at the end of a window that began at step e_ws (steps since t_begin) and became the best of some read(s) of the quad:
-    // improved = ballot of the lanes owning the last query row of those reads.  All 64 lanes are active here.
+    // at the end of a window that began at step e_ws (steps since t_begin; per lane: the value of the lane's read) and became the
+    // best of some read(s) of the quad: improved = ballot of the lanes owning the last query row of those reads.  All 64 lanes
+    // are active here.
     template <int R, int L, bool WT = false>  // WT: write-through stores (the fused launch reads the record in the same launch)
     __device__ __forceinline__ void save(unsigned long long improved, float wmin, int e_ws, int margin, int lq, int job, int shift) {
         const int lane = threadIdx.x & 63;
@@ -517,8 +548,8 @@ struct LdsCkpt {
 template <int R, bool TRACK, bool STD, int RQ, bool LCK = false, int L = 16, bool WT = false>
 __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
                                           const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<TRACK> &top,
-                                          const int job, float *ckp, const int T, IssuePriority &pr, LdsCkpt *lck = nullptr,
-                                          const bool owner = false) {
+                                          const int job, float *ckp, const int T, IssuePriority &pr, const MixedQuad &mq,
+                                          LdsCkpt *lck = nullptr, const bool owner = false) {
     typename Vec<float, R>::type cv;
     typename Vec<int, R>::type sv;
 #pragma unroll
@@ -598,13 +629,36 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     // steps start wherever the previous window ended (the 16-byte reference loads need no alignment), so the
     // steady-state block carries no window-end test at all. ----
     int jqv = 0;  // last-row column of the next step
+    // Windows.  std_dtw has one candidate per job, the tracking fill keeps one query length per wave: there a window is qlen
+    // columns for every read of the wave.  The cost-only subsequence fill (MIX) carries reads of different lengths (MixedQuad):
+    // every read has windows of its OWN length, so the sweep is cut wherever ANY read's window ends (wave-uniform: the slots'
+    // window ends live in scalar registers), and at such a point the reads whose window ends there offer their candidate and
+    // start a new one.  With equal lengths that is the old loop: one cut per window.
+    constexpr bool MIX = !TRACK && !STD;
+    constexpr bool CELL = CellFromFill<R, TRACK, STD>::value;
+    constexpr int NS = 64 / L;  // reads per wave
+    const int my_slot = (threadIdx.x & 63) / L;
+    int q_s[NS], ws_s[NS], we_s[NS];  // per slot: query length, first column and end of its current window
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        q_s[sl] = MIX ? __builtin_amdgcn_readlane(mq.myq, sl * L) : qlen;
+        ws_s[sl] = 0;
+        we_s[sl] = min(q_s[sl], rlen);
+    }
+    float wmin = INFINITY;
+    int wpos = CELL ? 0 : -1, wst = -1;
     for (int col = 0; col < rlen;) {
         if (!TRACK) pr.at_window(col);
-        const int wl = STD ? rlen : min(qlen, rlen - col);  // std_dtw has a single candidate: one "window"
+        int nxt = we_s[0];
+#pragma unroll
+        for (int sl = 1; sl < NS; ++sl) nxt = min(nxt, we_s[sl]);
+        const int wl = STD ? rlen : (MIX ? nxt - col : min(qlen, rlen - col));  // std_dtw has a single candidate: one "window"
         const int nb = wl >> 2, rm = wl & 3;
-        constexpr bool CELL = CellFromFill<R, TRACK, STD>::value;
-        float wmin = INFINITY;
-        int wpos = CELL ? col : -1, wst = -1;
+        if (!MIX) {
+            wmin = INFINITY;
+            wpos = CELL ? col : -1;
+            wst = -1;
+        }
         // Cost-only pass, 16-row shapes: only the window MINIMUM is kept (one v_min per step); which column attains it first
         // is settled in pass 2 for the single window that wins.  32-row shapes (CELL) also keep the column of the first strict
         // minimum.  With tracking (single-pass mode) the first strict minimum, its column and its start column are selected
@@ -659,13 +713,34 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             e += rm;
             ycur = ynext;
         }
-        if (!STD) {
+        if (MIX) {
+            // the reads whose window ends at column nxt (a lane mask from the scalar window ends), their window's first column
+            unsigned long long endmask = 0;
+            int wsl = ws_s[0];
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const unsigned long long lanes_of_slot = (L == 64) ? ~0ull : (((1ull << (L & 63)) - 1) << ((sl * L) & 63));
+                if (we_s[sl] == nxt) endmask |= lanes_of_slot;
+                if (sl > 0) wsl = (my_slot == sl) ? ws_s[sl] : wsl;
+            }
+            const bool ending = (endmask >> (threadIdx.x & 63)) & 1;
             // (cost-only, 16-row shapes: the window is identified by its first column)
-            const bool became_best = top.offer(wmin, (TRACK || CELL) ? wpos : col, wst, job);
+            const bool became_best = top.offer_if(ending, wmin, CELL ? wpos : wsl, wst, job);
             if (LCK) {
                 const unsigned long long improved = __ballot(became_best && owner);
-                if (improved) lck->template save<R, L, WT>(improved, wmin, col + e_main, a.trace_margin, lq, job, a.lck_shift);
+                if (improved) lck->template save<R, L, WT>(improved, wmin, wsl + e_main, a.trace_margin, lq, job, a.lck_shift);
             }
+            wmin = ending ? INFINITY : wmin;
+            if (CELL) wpos = ending ? nxt : wpos;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                if (we_s[sl] == nxt) {
+                    ws_s[sl] = nxt;
+                    we_s[sl] = min(nxt + q_s[sl], rlen);
+                }
+            }
+        } else if (!STD) {
+            top.offer(wmin, wpos, wst, job);  // (tracking fill: the first strict minimum of the window, its column and start)
         } else {  // std_dtw: the single candidate C[n-1][m-1]
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
             const int sl = TRACK ? ((RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq])) : 0;
@@ -681,14 +756,14 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
 template <int R, bool TRACK, bool STD, bool LCK = false, int L = 16, bool WT = false, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
                                                const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T,
-                                               IssuePriority &pr, LdsCkpt *lck = nullptr, bool owner = false) {
+                                               IssuePriority &pr, const MixedQuad &mq, LdsCkpt *lck = nullptr, bool owner = false) {
     if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
-        sweep_job<R, TRACK, STD, -1, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
+        sweep_job<R, TRACK, STD, -1, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
     } else {
         if (rq == I) {
-            sweep_job<R, TRACK, STD, I, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
+            sweep_job<R, TRACK, STD, I, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, LCK, L, WT, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, lck, owner);
+            sweep_dispatch<R, TRACK, STD, LCK, L, WT, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
         }
     }
 }
@@ -702,22 +777,24 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     const int lane = threadIdx.x & 63;
     const int g = lane & (L - 1);
     const int slot = lane / L;
-    const bool lane0 = (g == 0);
 
-    const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);
+    const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);  // the LONGEST read of the wave (all of them but for MixedQuad)
     const int read = a.order[quad * 4 + slot];
     const int lq = (qlen - 1) / R;  // lane / register holding the last query row (wave-uniform)
     const int rq = (qlen - 1) - lq * R;
     const int t_begin = sweep_begin(lq);
+    MixedQuad mq;
+    mq.template init<R>(a, read, qlen);
+    const bool lane0 = (g == mq.g0);
 #ifdef SFA_TASK_TIMES
     const int dbg_task = cd.task_base + task_local;
     if (a.task_times && lane == 0) a.task_times[3 * static_cast<int64_t>(dbg_task)] = wall_clock64();
 #endif
 
     float x[R];
-    load_query_rows<R>(x, a, read, qlen, g);
+    load_query_rows<R>(x, a, read, mq.myq, g, mq.g0);
     Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L, mq.g0);
 
     Top2<TRACK> top;
     top.init();
@@ -755,7 +832,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD, LCK, L, FUSED>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, &lck, g == lq && read >= 0);
+        sweep_dispatch<R, TRACK, STD, LCK, L, FUSED>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, &lck, g == lq && read >= 0);
     }
 
     if (g == lq && read >= 0) {
@@ -1119,17 +1196,19 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     const int lane = threadIdx.x & 63;
     const int g = lane & (L - 1);
     const int slot = lane / L;
-    const bool lane0 = (g == 0);
 
-    const int qlen = a.quad_qlen[quad];
+    const int qlen = a.quad_qlen[quad];  // the longest read of the wave: lane and register of everybody's last query row
     const int read = a.order[quad * 4 + slot];
     const int lq = (qlen - 1) / R;
     const int rq = (qlen - 1) - lq * R;
+    MixedQuad mq;  // this read's own length and the lane its query row 0 sits in
+    mq.template init<R>(a, read, qlen);
+    const bool lane0 = (g == mq.g0);
 
     float x[R];
-    load_query_rows<R>(x, a, read, qlen, g);
+    load_query_rows<R>(x, a, read, mq.myq, g, mq.g0);
     Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L);
+    xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L, mq.g0);
 
     int job = (read >= 0) ? w.job : -1;
     constexpr bool CELL = CellFromFill<R, false, STD>::value && !LCK;
@@ -1138,7 +1217,7 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     bool done = !(read >= 0 && job >= 0 && ws >= 0);
     job = done ? 0 : job;
     const int rlen = a.job_len[job];
-    const int wl = STD ? 1 : min(qlen, rlen - ws);  // std_dtw: the "window" is the last column alone
+    const int wl = STD ? 1 : min(mq.myq, rlen - ws);  // the read's own window length; std_dtw: the "window" is the last column alone
     const int t_begin = sweep_begin(lq);             // same time origin as the fill
     const float *ybase = a.ref + a.job_off[job] - g;
     const int t_first = ws + lq;            // step at which lane lq evaluates the first cell of the window
@@ -1230,7 +1309,7 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u) {
                 const int t = tb + tau0 + u;
-                dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t, lane0, xc);
+                dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t - mq.g0, lane0, xc);  // (the column of the lane holding row 0)
                 const float cl = c[rq];
                 const int sl = s[rq];
                 const bool hit = (cap_end < 0) && !bad_rec && (t >= t_first) && (t <= t_last) && (cl == best);

@@ -216,6 +216,7 @@ struct sfa_ctx {
     int64_t opt_fused_trace = 1;             // 1: with LDS checkpoints, pass 2 rides in the fill launch as trailing tickets (fills the drain)
     int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
     int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
+    int64_t opt_mixed_quads = 1;             // reads of different lengths (equal modulo the rows per lane) may share a wave
     int64_t opt_spin_limit_ms = 20000;       // bound of every in-launch wait (fused pass 2, pipelined strips); beyond it the batch fails with SFA_EKERNEL
     int64_t opt_debug_drop_quad = -1;        // test hook: the fill tasks of this quad never signal completion
     int64_t opt_debug_drop_strip = -1;       // test hook: strip 0 of this long read (job 0) never publishes its progress
@@ -592,6 +593,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.allow_segments = !(c->flag & SFA_DTW) && !c->no_segments_once;
     pp.lds_ckpt = static_cast<int>(c->opt_lds_ckpt);
     pp.std_dtw = (c->flag & SFA_DTW) != 0;
+    pp.mixed_quads = c->opt_mixed_quads != 0;
     std::vector<int32_t> long_reads;  // queries beyond the wave kernels' 2048 events: row strips, after the rest of the batch
     int64_t long_events = 0, long_max = 0;
     for (int32_t i = 0; i < n; ++i)
@@ -1217,6 +1219,8 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "prio_unit") {
         if (value < 0 || value > (1 << 28)) return fail(SFA_EINVAL, "prio_unit must be 0 (off) .. 2^28");
         c->opt_prio_unit = value;
+    } else if (k == "mixed_quads") {
+        c->opt_mixed_quads = value != 0;
     } else if (k == "spin_limit_ms") {
         if (value < 1 || value > 3600000) return fail(SFA_EINVAL, "spin_limit_ms must be 1 .. 3 600 000");
         c->opt_spin_limit_ms = value;

@@ -2,9 +2,11 @@
 //
 // Replaces the reference's per-batch thread fan-out (work_db / pthread_db, src/thread.c:74-132: contiguous
 // read ranges per thread + work stealing) with a static plan for the GPU:
-//   * reads of EQUAL query length are grouped four at a time into "quads" (one wavefront each); lengths select
-//     a rows-per-lane class R (4/8/16/32) -- long classes first so that short work fills the tail; queries of
-//     513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read per "quad";
+//   * reads are grouped four at a time into "quads" (one wavefront each); lengths select a rows-per-lane class R
+//     (4/8/16/32) -- long classes first so that short work fills the tail; inside a class reads whose lengths agree
+//     modulo R share waves (lengths descending; MixedQuad in sdtw_kernels.hpp), std_dtw and the tracking fill keep ONE
+//     length per wave; queries of 513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read
+//     per "quad";
 //   * SMALL BATCHES: when the waves of a batch would not fill the chip, every class trades rows per lane for lanes
 //     per read (R/2 x 2L or R/4 x 4L, "lane widening" 2 or 4): 2-4x the waves, each with a 2-4x shorter step;
 //   * the (contig,strand) job list is cut into contiguous chunks of similar size when there are too few quads
@@ -62,6 +64,7 @@ struct PlanParams {
     int64_t segment_warm_windows = 4;  // windows (query lengths) a segment starts before its own first one
     bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory) and single pass
     int lds_ckpt = 0;               // 1: rolling checkpoints in LDS + sparse HBM checkpoints (sdtw_kernels.hpp, LdsCkpt) where the shapes allow and the batch size suits; 2: wherever the shapes allow
+    bool mixed_quads = true;        // reads of different lengths (equal modulo the rows per lane) may share a wave (sdtw_kernels.hpp, MixedQuad)
     bool std_dtw = false;           // --dtw-std: with lds_ckpt the fill keeps NO LDS snapshots, only the sparse HBM store (the margin is not capped)
     bool skip_long = false;         // true: reads of more than kMaxQuery events are left out (the caller runs them in row strips, sdtw_strips.hpp)
 };
@@ -87,7 +90,7 @@ struct BatchPlan {
     // scratch of plan_batch(), kept with the plan: a caller that reuses one BatchPlan for every batch (the library does)
     // pays no allocation in the steady state -- the vectors of a 100 000-read plan are 400 KB each, i.e. one mmap / page-fault
     // round per vector and call otherwise (1.35 -> 0.75 ms per plan)
-    std::vector<int32_t> s_qlen, s_count, s_quad_start, s_fill_pos;
+    std::vector<int32_t> s_qlen, s_count, s_fill_pos, s_slot_start, s_len_quad_base;
     std::vector<int8_t> s_per_shift;
     void reset() {  // scalars back to their defaults; vectors keep their capacity
         n_quads = 0; n_chunks = 1; max_R = 4; max_lanes = 16; widening = 1; ck_shift = 0; trace_margin = 0; lck_shift = 9;
@@ -120,7 +123,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     p.reset();
     p.single_pass = pp.single_pass;
     const int32_t n_jobs = static_cast<int32_t>(job_len.size());
-    std::vector<int32_t> &qlen = p.s_qlen, &count = p.s_count, &quad_start = p.s_quad_start, &fill_pos = p.s_fill_pos;
+    std::vector<int32_t> &qlen = p.s_qlen, &count = p.s_count, &fill_pos = p.s_fill_pos;
     qlen.assign(n, 0);
     count.assign(kMaxQuery + 2, 0);
     int maxq = 0;
@@ -142,7 +145,6 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     }
     // classes in task order (long first); inside a class by descending length.  layout(w) fills the plan for lane
     // widening w and returns the number of quads (waves' worth of reads).
-    quad_start.assign(maxq + 2, -1);
     // Queries of 257 .. 1024 events on the LDS-checkpoint route: their base shapes hold 32 rows per lane (16 or 32 lanes per
     // read), whose snapshots (33 planes) do not fit LDS twice at four waves per SIMD.  The same queries fit 16 rows x 32 / 64
     // lanes (two reads / one read per wave) -- the shapes of "lane widening" 2 --, which run the 16-row kernels: rolling
@@ -157,9 +159,20 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // launches, not time.  It is therefore taken only on request (lds_ckpt = 2); lds_ckpt = 1 keeps the 32-row kernels.
     const bool r32_as_r16 = pp.lds_ckpt >= 2 && !pp.single_pass && pp.ckpt_interval == 0 && maxq > 256 && maxq <= 1024;
     auto class_widening = [&](int ci, int w) { return (r32_as_r16 && (ci == 1 || ci == 2)) ? std::max(w, 2) : w; };
+    // MIXED QUADS (sdtw_kernels.hpp, MixedQuad): reads of different lengths share a wave when their lengths agree modulo the
+    // rows per lane R of their class -- every read's last query row then falls into the same lane and register.  A class is laid
+    // out residue by residue, lengths descending inside a residue, a new wave only where a residue ends: a ragged batch with a few
+    // hundred distinct lengths leaves at most R partly filled waves per class instead of one per length.  Not for std_dtw and
+    // the tracking fill (their kernels keep one length per wave) nor at lane widening 4 (the column segments align on ONE
+    // query length).
+    auto mixing = [&](int w) { return pp.mixed_quads && !pp.single_pass && !pp.std_dtw && w < 4; };
+    std::vector<int32_t> &slot_start = p.s_slot_start, &len_quad_base = p.s_len_quad_base;
+    slot_start.assign(maxq + 2, 0);
+    len_quad_base.assign(maxq + 2, 0);
     auto layout = [&](int w) {
         p.classes.clear();
         int32_t n_quads = 0;
+        const bool mix = mixing(w);
         for (int ci = 0; ci < 6; ++ci) {
             const ClassShape sh = widened(ci, class_widening(ci, w));
             PlanClass cl;
@@ -167,11 +180,19 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
             cl.lanes = sh.lanes;
             cl.quad_base = n_quads;
             const int per = 64 / cl.lanes;  // reads per wave
-            for (int l = maxq; l >= 1; --l) {
-                if (count[l] == 0 || class_for(l) != ci) continue;
-                quad_start[l] = n_quads;
-                n_quads += (count[l] + per - 1) / per;
+            int32_t pos = 0;                // reads placed in this class so far (slot index inside the class)
+            const int n_res = mix ? cl.R : 1;
+            for (int res = 0; res < n_res; ++res) {
+                for (int l = maxq; l >= 1; --l) {
+                    if (count[l] == 0 || class_for(l) != ci || (mix && l % cl.R != res)) continue;
+                    slot_start[l] = pos;
+                    len_quad_base[l] = cl.quad_base;
+                    pos += count[l];
+                    if (!mix) pos = (pos + per - 1) / per * per;  // one length per wave
+                }
+                pos = (pos + per - 1) / per * per;  // a new residue starts a new wave
             }
+            n_quads += pos / per;
             cl.n_quads = n_quads - cl.quad_base;
             if (cl.n_quads > 0) p.classes.push_back(cl);
         }
@@ -209,7 +230,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         p.max_lanes = std::max(p.max_lanes, cl.lanes);
     }
     p.order.assign(4 * static_cast<size_t>(std::max(n_quads, 1)), -1);
-    p.quad_qlen.assign(std::max(n_quads, 1), 1);
+    p.quad_qlen.assign(std::max(n_quads, 1), 0);
     p.slot_of_read.assign(n, -1);
     fill_pos.assign(maxq + 2, 0);
     std::vector<int8_t> &per_shift = p.s_per_shift;
@@ -222,17 +243,15 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     for (int32_t i = 0; i < n; ++i) {
         const int l = qlen[i];
         if (l == 0) continue;
-        const int32_t k = fill_pos[l]++;
+        const int32_t k = slot_start[l] + fill_pos[l]++;  // position inside the class
         const int sh = per_shift[l];
-        const int32_t sl = (quad_start[l] + (k >> sh)) * 4 + (k & ((1 << sh) - 1));  // a wave always has four slots; wide shapes use 2 / 1
+        const int32_t qd = len_quad_base[l] + (k >> sh);
+        const int32_t sl = qd * 4 + (k & ((1 << sh) - 1));  // a wave always has four slots; wide shapes use 2 / 1
         p.order[sl] = i;
         p.slot_of_read[i] = sl;
+        p.quad_qlen[qd] = std::max(p.quad_qlen[qd], l);  // the wave's longest read: where everybody's last query row sits
     }
-    for (int l = 1; l <= maxq; ++l)
-        if (count[l]) {
-            const int per = 64 / widened(class_for(l), class_widening(class_for(l), w)).lanes;
-            for (int32_t qd = quad_start[l]; qd < quad_start[l] + (count[l] + per - 1) / per; ++qd) p.quad_qlen[qd] = l;
-        }
+    if (n_quads == 0) p.quad_qlen[0] = 1;
 
     // column segments: when even one wave per (read, job) leaves the chip idle, every job is cut into segments that
     // start from a guessed state a few windows early and are verified against their predecessor (sweep_segment)

@@ -99,8 +99,14 @@ def test_plan_batch_layout():
     used = slot[lens > 0]
     assert len(np.unique(used)) == len(used)            # one slot per read
     quads = used >> 2
-    for qd in np.unique(quads):                          # a quad holds reads of ONE length
-        assert len(set(lens[lens > 0][quads == qd])) == 1
+    rows_per_lane = lambda l: 4 if l <= 64 else 8 if l <= 128 else 16 if l <= 256 else 32
+    mixed = 0
+    for qd in np.unique(quads):      # a quad holds reads of ONE class whose lengths agree modulo the rows per lane (MixedQuad)
+        ls = lens[lens > 0][quads == qd]
+        R = rows_per_lane(int(ls.max()))
+        assert {rows_per_lane(int(l)) for l in ls} == {R} and len({int(l) % R for l in ls}) == 1, ls
+        mixed += len(set(ls)) > 1
+    assert mixed >= 1                # 1 and 25 events: both 1 modulo 4
     assert info["n_quads"] == len(np.unique(quads))
     assert info["n_classes"] == 4 and info["max_rows_per_lane"] == 32
     assert 1 <= info["n_chunks"] <= 2 and info["n_tasks"] == info["n_quads"] * info["n_chunks"]
@@ -184,3 +190,24 @@ def test_plan_batch_empty_and_single():
     assert info["n_quads"] == 0 and (slot == -1).all()
     info, slot = plan_batch(np.array([0, 7], np.int64), [50])
     assert info["n_quads"] == 1 and slot[0] == 0
+
+
+def test_plan_batch_ragged_lengths_share_waves():
+    """A ragged batch (hundreds of distinct lengths, a read or two of each) used to take a wave per length; with reads whose
+    lengths agree modulo the rows per lane sharing waves, a class leaves at most that many partly filled waves."""
+    from sigfish_amd.api import plan_batch
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([np.full(7782, 250), rng.integers(25, 250, size=410)])  # 8 192 reads, 5 % shorter
+    rng.shuffle(lens)
+    q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    info, slot = plan_batch(q_off, [29898, 29898], lane_widening=1)
+    assert len(np.unique(slot)) == len(slot)
+    # reads / 4 plus at most one partly filled wave per residue of each class: 4 + 8 + 16
+    assert info["n_quads"] <= (len(lens) + 3) // 4 + 28
+    assert info["n_quads"] <= 1.03 * len(lens) / 4     # (one wave per length would be ~2 170)
+    # inside a wave the longest read comes first (it fixes where the last query row sits)
+    order = np.argsort(slot)
+    quads = slot[order] >> 2
+    for qd in np.unique(quads)[:200]:
+        ls = lens[order][quads == qd]
+        assert (np.diff(ls) <= 0).all()
