@@ -346,6 +346,13 @@ int sfa_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
  * when the decoder declines the stream (the reader then falls back to zlib's inflate). */
 int64_t sfa_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap);
 
+/* The same for TWO streams decoded side by side by the calling thread (how the reader's host threads take records: the symbol
+ * loops of the two streams take turns, two dependence chains keep a core busier than one).  len[k] receives what
+ * sfa_inflate_zlib would return for stream k -- a stream that is declined does not disturb the other.  Returns SFA_OK, or
+ * SFA_EINVAL for null arguments. */
+int sfa_inflate_zlib_pair(const uint8_t *in0, size_t n0, const uint8_t *in1, size_t n1, uint8_t *out0, size_t cap0, uint8_t *out1,
+                          size_t cap1, int64_t len[2]);
+
 #ifdef __cplusplus
 }
 #endif

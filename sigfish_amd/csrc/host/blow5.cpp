@@ -281,6 +281,11 @@ bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::
     return parse_blow5_record(mem, size, record_press_ == 1, signal_press_ == 1, rec, err);
 }
 
+namespace {
+// the fields and the signal of one record from its (inflated) payload [p, end)
+bool parse_payload(const uint8_t *p, const uint8_t *end, int signal_svb, Blow5Record *rec, std::string *err);
+}  // namespace
+
 bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int signal_svb, Blow5Record *rec, std::string *err) {
     rec->record_bytes = size;
     const uint8_t *p = mem, *end = p + size;
@@ -294,6 +299,35 @@ bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int si
         p = inflated;
         end = p + inflated_len;
     }
+    return parse_payload(p, end, signal_svb, rec, err);
+}
+
+// Two records by one thread: their zlib streams are inflated side by side (inflate.hpp: two dependence chains keep a core busier
+// than one); everything else is parse_blow5_record's, and so is the result -- a record the paired decoder declines goes through
+// the single-record path (own decoder, then zlib), errors are reported per record.
+void parse_blow5_record_pair(const uint8_t *const mem[2], const size_t size[2], int record_zlib, int signal_svb, Blow5Record *const rec[2],
+                             std::string *const err[2], bool ok[2]) {
+    if (!record_zlib) {
+        for (int k = 0; k < 2; ++k) ok[k] = parse_blow5_record(mem[k], size[k], record_zlib, signal_svb, rec[k], err[k]);
+        return;
+    }
+    thread_local std::vector<uint8_t> buf0, buf1;
+    std::vector<uint8_t> *const bufs[2] = {&buf0, &buf1};
+    size_t len[2] = {0, 0};
+    bool inflated[2];
+    fast_inflate_zlib_pair(mem, size, bufs, len, inflated);
+    for (int k = 0; k < 2; ++k) {
+        if (!inflated[k]) {  // declined: the single-record path decides (zlib's own inflate as the last word)
+            ok[k] = parse_blow5_record(mem[k], size[k], record_zlib, signal_svb, rec[k], err[k]);
+            continue;
+        }
+        rec[k]->record_bytes = size[k];
+        ok[k] = parse_payload(bufs[k]->data(), bufs[k]->data() + len[k], signal_svb, rec[k], err[k]);
+    }
+}
+
+namespace {
+bool parse_payload(const uint8_t *p, const uint8_t *end, int signal_svb, Blow5Record *rec, std::string *err) {
     uint16_t idlen;
     uint64_t len;
     bool ok = take(p, end, &idlen) && static_cast<size_t>(end - p) >= idlen;
@@ -316,6 +350,11 @@ bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int si
     }
     if (!ok) *err = "malformed BLOW5 record (read " + rec->read_id + ")";
     return ok;
+}
+}  // namespace
+
+void Blow5Reader::parse_pair(const uint8_t *const mem[2], const size_t size[2], Blow5Record *const rec[2], std::string *const err[2], bool ok[2]) const {
+    parse_blow5_record_pair(mem, size, record_press_ == 1, signal_press_ == 1, rec, err, ok);
 }
 
 int Blow5Reader::next(Blow5Record *rec) {

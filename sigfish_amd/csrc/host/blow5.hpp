@@ -29,6 +29,9 @@ struct Blow5Record {
 // One record's bytes -> fields + samples, given the file's compression methods (what Blow5Reader::parse does; free-standing
 // for callers that hold record bytes without a reader, e.g. the fallback of the device-side decoder)
 bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int signal_svb, Blow5Record *rec, std::string *err);
+// ... and two of them by one thread, their zlib streams inflated side by side (same results, record by record)
+void parse_blow5_record_pair(const uint8_t *const mem[2], const size_t size[2], int record_zlib, int signal_svb, Blow5Record *const rec[2],
+                             std::string *const err[2], bool ok[2]);
 
 class Blow5Reader {
   public:
@@ -45,6 +48,7 @@ class Blow5Reader {
     // zero-copy variant: the file is mapped, a record is a (pointer, size) view into the mapping (valid until close())
     int next_view(const uint8_t **mem, size_t *size);
     bool parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const;
+    void parse_pair(const uint8_t *const mem[2], const size_t size[2], Blow5Record *const rec[2], std::string *const err[2], bool ok[2]) const;
     // first value (read group 0) of a header attribute, or nullptr (slow5_hdr_get(attr, 0, hdr))
     const char *attr(const std::string &key) const;
     uint32_t num_read_groups() const { return n_groups_; }

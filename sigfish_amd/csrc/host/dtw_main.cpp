@@ -43,6 +43,7 @@ struct Opt {
     std::vector<int> devices{0};  // --device 0,1,...: batches go to the devices in turn
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
     int gpu_parse = -1;        // --gpu-parse / --host-parse: records decompressed and parsed on the GPU / on host threads (-1: by device count)
+    int hybrid_every = -1;     // --hybrid-parse N: every Nth batch goes to the device as it is in the file, the others through host threads (0: off, -1: auto)
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     const char *model_file = nullptr;
     const char *pore = nullptr;
@@ -96,7 +97,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [4 for compressed files on up to 2 GPUs]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -224,7 +225,7 @@ static int dtw_run(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   {"hybrid-parse", required_argument, 0, 18},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -278,6 +279,10 @@ static int dtw_run(int argc, char **argv) {
             case 14: o.host_events = true; break;
             case 16: o.gpu_parse = 0; break;
             case 17: o.gpu_parse = 1; break;
+            case 18:
+                o.hybrid_every = atoi(optarg);
+                if (o.hybrid_every < 0 || o.hybrid_every == 1) die("--hybrid-parse takes 0 (off) or an integer >= 2 (use --gpu-parse for every batch)");
+                break;
             case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }
@@ -411,6 +416,7 @@ static int dtw_run(int argc, char **argv) {
         std::vector<sfa_read_head_t> heads;
         int32_t n = 0;
         int64_t bytes = 0;
+        bool via_device = false;  // this batch's records go to the device as they are in the file (sfa_align_blow5)
     };
     // events on the GPU unless the RNA auto prefix is asked for (adaptor/poly-A detection stays on the host); for SAM the
     // event tables of the query windows come back from the device with the rows
@@ -422,6 +428,14 @@ static int dtw_run(int argc, char **argv) {
     // LDS -- and the host route is the better one at the default -K 4096.  What the device route buys is independence from the
     // host: a node's cores do not grow with its GPUs, so it is the default from three devices on.
     const bool gpu_parse = gpu_events && (o.gpu_parse < 0 ? o.devices.size() > 2 : o.gpu_parse == 1);
+    // ... or some of them (round 3): the two routes load DIFFERENT resources -- the host route's inflate keeps the -t threads busy
+    // (27 us per record and core) while the device idles half of the time, the device route costs the host a memcpy and the
+    // device a decode it has room for.  Every Nth batch on the device route, the others on the host route: with N = 4 a group of
+    // four 4 096-read batches costs the main thread 7 + 7 + 7 + 1 ms and the device 4 x 4.2 + 4 ms -- both busy, neither waiting
+    // (profiles/r03_logs/e2e_hybrid_parse.log).  Only where there is something to inflate (zlib records) and host-route is the
+    // choice anyway; rows and text are the same whichever route a batch takes (all CLI goldens run host, device and hybrid).
+    const int hybrid_every = (!gpu_events || gpu_parse || o.gpu_parse == 0 || prf) ? 0
+                             : (o.hybrid_every >= 0 ? o.hybrid_every : ((reader.records_zlib() && o.devices.size() <= 2) ? 4 : 0));
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);
@@ -438,7 +452,7 @@ static int dtw_run(int argc, char **argv) {
         const int32_t n = sl.n;
         std::vector<sfa_result_t> &rows = sl.rows;
         const double a = realtime();
-        if (gpu_parse) {
+        if (sl.via_device) {
             sl.info.resize(n);
             sl.heads.resize(n);
             if (sam) sl.qev.resize(static_cast<size_t>(n) * o.query);
@@ -493,7 +507,7 @@ static int dtw_run(int argc, char **argv) {
                 const int64_t qs = gpu_events ? 0 : r.qstart, qe = gpu_events ? sl.info[i].qend - sl.info[i].qstart : r.qend;
                 const float *y = row.strand == '+' ? fwd[row.rid].data() : rev[row.rid].data();
                 std::string buf(1 << 16, '\0');
-                const char *rid = gpu_parse ? sl.heads[i].read_id : r.rec.read_id.c_str();
+                const char *rid = sl.via_device ? sl.heads[i].read_id : r.rec.read_id.c_str();
                 int len = sfa_sam_row(&buf[0], buf.size(), &row, rid, contigs[row.rid].name.c_str(), ev, qs, qe, y,
                                       ref_len[row.rid], ref_off[row.rid], o.flag);
                 if (len == SFA_ERANGE) {  // very long ss strings (full-reference alignments)
@@ -521,8 +535,8 @@ static int dtw_run(int argc, char **argv) {
                     end_raw = static_cast<uint64_t>(static_cast<float>(e1.start) + e1.length);  // u64 + float, as in C
                     qsize = static_cast<uint64_t>((r.qend - 1) - r.qstart);
                 }
-                const char *rid = gpu_parse ? sl.heads[i].read_id : r.rec.read_id.c_str();
-                const uint64_t n_raw = gpu_parse ? static_cast<uint64_t>(sl.heads[i].n_samples) : r.rec.raw.size();
+                const char *rid = sl.via_device ? sl.heads[i].read_id : r.rec.read_id.c_str();
+                const uint64_t n_raw = sl.via_device ? static_cast<uint64_t>(sl.heads[i].n_samples) : r.rec.raw.size();
                 const int len = sfa_paf_row(&line[0], line.size(), &rows[i], rid, contigs[rows[i].rid].name.c_str(),
                                             start_raw, end_raw, qsize, n_raw, static_cast<uint64_t>(seq_len[rows[i].rid]));
                 if (len < 0) die("PAF line too long");
@@ -561,6 +575,7 @@ static int dtw_run(int argc, char **argv) {
         }
         sl.n = n;
         sl.bytes = bytes;
+        sl.via_device = gpu_parse || (hybrid_every > 0 && bi % hybrid_every == hybrid_every - 1);
         t_load += realtime() - a;
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
@@ -587,7 +602,7 @@ static int dtw_run(int argc, char **argv) {
                 r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), static_cast<int64_t>(r.rec.raw.size()), pa.data(), o.prefix, o.query,
                                                    o.flag, o.pore_flag, &r.qstart, &r.qend, &r.status);
         };
-        if (gpu_parse) {  // nothing to parse here: the records go to the device as they are
+        if (sl.via_device) {  // nothing to parse here: the records go to the device as they are
             double b = realtime();
             sl.rec_off.resize(n + 1);
             sl.rec_off[0] = 0;
@@ -605,12 +620,35 @@ static int dtw_run(int argc, char **argv) {
             });
             t_parse += realtime() - b;
         } else if (!prf) {  // one fan-out per batch, every read through all its host stages (work_per_single_read, src/sigfish.c:995-1001)
-            pool.run(n, [&](int64_t i) {
-                parse_one(i);
+            auto rest_of = [&](int64_t i) {
                 if (bad || gpu_events || batch[i].rec.raw.empty()) return;
                 std::vector<float> pa;
                 events_one(i, pa);
                 normalise_one(i, pa);
+            };
+            // reads go two at a time: their zlib streams are inflated side by side by one thread (blow5.hpp: parse_pair)
+            pool.run((n + 1) / 2, [&](int64_t j) {
+                const int64_t i0 = 2 * j, i1 = 2 * j + 1;
+                if (i1 >= n) {
+                    parse_one(i0);
+                } else {
+                    Read &a0 = batch[i0], &a1 = batch[i1];
+                    const uint8_t *const mem[2] = {a0.view ? a0.view : a0.mem.data(), a1.view ? a1.view : a1.mem.data()};
+                    const size_t size[2] = {a0.view_size, a1.view_size};
+                    sfa::Blow5Record *const rec[2] = {&a0.rec, &a1.rec};
+                    std::string e0, e1;
+                    std::string *const err[2] = {&e0, &e1};
+                    bool ok[2];
+                    reader.parse_pair(mem, size, rec, err, ok);
+                    if (!ok[0] || !ok[1]) bad = 1;
+                    for (Read *r : {&a0, &a1}) {
+                        r->keep = false;
+                        r->ev.clear();
+                        r->status = 0;
+                    }
+                    rest_of(i1);
+                }
+                rest_of(i0);
             });
         } else {  // stage by stage, each under its timer
             double b = realtime();
@@ -631,7 +669,7 @@ static int dtw_run(int argc, char **argv) {
             }
         }
         if (bad) die("error parsing a BLOW5 record");
-        if (gpu_events && !gpu_parse) {  // pack the samples of the batch for one upload
+        if (gpu_events && !sl.via_device) {  // pack the samples of the batch for one upload
             sl.raw_off.resize(n + 1);
             sl.scaling.resize(3 * static_cast<size_t>(n));
             sl.raw_off[0] = 0;

@@ -1,12 +1,63 @@
 // inflate.cpp -- see inflate.hpp.  Written against RFC 1950 (zlib wrapper) and RFC 1951 (DEFLATE) only.
 #include "inflate.hpp"
 
-#include <zlib.h>  // adler32() for the trailer check
+#include <immintrin.h>
 
 #include <cstring>
 
 namespace sfa {
 namespace {
+
+// Adler-32 (RFC 1950) of the inflated record, 32 bytes per step with SSSE3 (zlib's adler32() on this image is the scalar
+// loop: 1.9 us per 6 KB record, a tenth of the whole decode); scalar tail and fallback for machines without SSSE3.
+inline uint32_t adler32_scalar(uint32_t adler, const uint8_t *p, size_t n) {
+    uint32_t a = adler & 0xffffu, b = adler >> 16;
+    while (n) {
+        size_t k = n < 5552 ? n : 5552;  // the largest run for which b cannot overflow 32 bits
+        n -= k;
+        while (k--) {
+            a += *p++;
+            b += a;
+        }
+        a %= 65521u;
+        b %= 65521u;
+    }
+    return (b << 16) | a;
+}
+__attribute__((target("ssse3"))) uint32_t adler32_ssse3(uint32_t adler, const uint8_t *p, size_t n) {
+    uint32_t a = adler & 0xffffu, b = adler >> 16;
+    const __m128i w_hi = _mm_setr_epi8(32, 31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17);
+    const __m128i w_lo = _mm_setr_epi8(16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1);
+    const __m128i ones = _mm_set1_epi16(1), zero = _mm_setzero_si128();
+    while (n >= 32) {
+        size_t blocks = n / 32;
+        if (blocks > 5552 / 32) blocks = 5552 / 32;
+        n -= blocks * 32;
+        // over a run of 32-byte blocks: a' = a + sum(bytes); b' = b + 32 * (a at the start of every block, summed) + sum of the weighted bytes
+        __m128i v_a = zero, v_b = zero, v_a_sum = zero;  // byte sums so far (per lane), weighted sums, sum over blocks of "byte sums before the block"
+        for (size_t i = 0; i < blocks; ++i, p += 32) {
+            const __m128i x0 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p)), x1 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p + 16));
+            v_a_sum = _mm_add_epi32(v_a_sum, v_a);
+            v_a = _mm_add_epi32(v_a, _mm_add_epi32(_mm_sad_epu8(x0, zero), _mm_sad_epu8(x1, zero)));
+            v_b = _mm_add_epi32(v_b, _mm_madd_epi16(_mm_maddubs_epi16(x0, w_hi), ones));
+            v_b = _mm_add_epi32(v_b, _mm_madd_epi16(_mm_maddubs_epi16(x1, w_lo), ones));
+        }
+        auto hsum = [](__m128i v) {
+            v = _mm_add_epi32(v, _mm_shuffle_epi32(v, 0x4e));
+            v = _mm_add_epi32(v, _mm_shuffle_epi32(v, 0xb1));
+            return static_cast<uint32_t>(_mm_cvtsi128_si32(v));
+        };
+        b += static_cast<uint32_t>(blocks) * 32u * a + 32u * hsum(v_a_sum) + hsum(v_b);
+        a += hsum(v_a);
+        a %= 65521u;
+        b %= 65521u;
+    }
+    return n ? adler32_scalar((b << 16) | a, p, n) : ((b << 16) | a);
+}
+inline uint32_t adler32_fast(const uint8_t *p, size_t n) {
+    static const bool have_ssse3 = __builtin_cpu_supports("ssse3");
+    return have_ssse3 ? adler32_ssse3(1u, p, n) : adler32_scalar(1u, p, n);
+}
 
 constexpr int kLitBits = 10;   // primary lookup width of the literal/length table
 constexpr int kDistBits = 8;   // ... of the distance table
@@ -185,62 +236,90 @@ struct Scratch {
     uint32_t lit[kLitCap], dist[kDistCap], clen[1 << kClenBits];
 };
 
-// returns 0 ok, 1 output full (grow and retry), -1 malformed
-int inflate_raw(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *produced, size_t *consumed, Scratch &sc) {
-    static const FixedTables fixed;
-    sc.in.resize(n + 16);
-    memcpy(sc.in.data(), src, n);
-    memset(sc.in.data() + n, 0, 16);
+// One DEFLATE stream being decoded, as a machine that advances in STEPS (a block header, or one trip of the symbol loop: up to
+// three literals or one match).  A single stream runs its steps back to back.  TWO streams take turns (inflate_pair): the
+// decoding of a symbol is one long dependence chain -- bit buffer -> table index -> load -> shift -> next index, 8-9 cycles on a
+// core that could issue four instructions per cycle -- and two independent chains side by side fill what one leaves idle
+// (measured on the fixture's records: 26.7 -> see profiles/r03_logs/host_inflate_pairs.log us per record and core).
+struct Stream {
+    enum State : int { kHeader = 0, kSymbols = 1, kDone = 2, kMalformed = -1, kFull = 3 };
     Bits b;
-    b.in = sc.in.data();
-    b.lim = sc.in.data() + n + 8;
-    uint8_t *o = out, *const oend = out + cap;  // the caller leaves >= 8 bytes of slack behind oend... see fast_inflate_zlib
-    for (;;) {
-        if (!b.refill()) return -1;
-        const uint32_t final = b.take(1), type = b.take(2);
-        const uint32_t *lit, *dist;
+    const uint8_t *in_base = nullptr;
+    size_t n = 0;
+    uint8_t *out = nullptr, *o = nullptr, *oend = nullptr;
+    const uint32_t *lit = nullptr, *dist = nullptr;
+    Scratch *sc = nullptr;
+    uint32_t final = 0;
+    int state = kDone;
+
+    void begin(const uint8_t *src, size_t len, uint8_t *dst, size_t cap, Scratch &scratch) {
+        sc = &scratch;
+        sc->in.resize(len + 16);
+        memcpy(sc->in.data(), src, len);
+        memset(sc->in.data() + len, 0, 16);
+        in_base = sc->in.data();
+        n = len;
+        b = Bits();
+        b.in = in_base;
+        b.lim = in_base + len + 8;
+        out = o = dst;
+        oend = dst + cap;  // the caller leaves >= 8 bytes of slack behind oend
+        final = 0;
+        state = kHeader;
+    }
+    bool active() const { return state == kHeader || state == kSymbols; }
+
+    // block header: stored blocks are copied whole; fixed / dynamic blocks set the tables up
+    void header() {
+        static const FixedTables fixed;
+        if (!b.refill()) return fail();
+        final = b.take(1);
+        const uint32_t type = b.take(2);
         if (type == 0) {  // stored: back to the byte boundary, the bytes still sitting in the bit buffer are un-read
             b.drop(b.cnt & 7u);
             b.in -= b.cnt >> 3;
             b.buf = 0;
             b.cnt = 0;
-            if (b.in + 4 > sc.in.data() + n) return -1;
+            if (b.in + 4 > in_base + n) return fail();
             const uint32_t len = b.in[0] | (static_cast<uint32_t>(b.in[1]) << 8), nlen = b.in[2] | (static_cast<uint32_t>(b.in[3]) << 8);
-            if ((len ^ nlen) != 0xffffu) return -1;
+            if ((len ^ nlen) != 0xffffu) return fail();
             b.in += 4;
-            if (b.in + len > sc.in.data() + n) return -1;
-            if (o + len > oend) return 1;
+            if (b.in + len > in_base + n) return fail();
+            if (o + len > oend) {
+                state = kFull;
+                return;
+            }
             memcpy(o, b.in, len);
             o += len;
             b.in += len;
-            if (final) break;
-            continue;
+            state = final ? kDone : kHeader;
+            return;
         }
         if (type == 1) {
             lit = fixed.lit;
             dist = fixed.dist;
         } else if (type == 2) {
             const uint32_t hlit = b.take(5) + 257, hdist = b.take(5) + 1, hclen = b.take(4) + 4;
-            if (hlit > 286 || hdist > 30) return -1;
+            if (hlit > 286 || hdist > 30) return fail();
             static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint8_t cl[19] = {0};
             for (uint32_t i = 0; i < hclen; ++i) {
-                if (b.cnt < 3 && !b.refill()) return -1;
+                if (b.cnt < 3 && !b.refill()) return fail();
                 cl[order[i]] = static_cast<uint8_t>(b.take(3));
             }
-            if (!build_table(cl, 19, 2, kClenBits, sc.clen, 1 << kClenBits)) return -1;
+            if (!build_table(cl, 19, 2, kClenBits, sc->clen, 1 << kClenBits)) return fail();
             uint8_t lens[286 + 30 + 138];
             uint32_t i = 0;
             while (i < hlit + hdist) {
-                if (!b.refill()) return -1;
-                const uint32_t e = sc.clen[b.peek(kClenBits)];
-                if (e_kind(e) != kLiteral || e_bits(e) == 0) return -1;
+                if (!b.refill()) return fail();
+                const uint32_t e = sc->clen[b.peek(kClenBits)];
+                if (e_kind(e) != kLiteral || e_bits(e) == 0) return fail();
                 b.drop(e_bits(e));
                 const uint32_t sym = e_value(e);
                 if (sym < 16) {
                     lens[i++] = static_cast<uint8_t>(sym);
                 } else if (sym == 16) {
-                    if (i == 0) return -1;
+                    if (i == 0) return fail();
                     const uint32_t rep = 3 + b.take(2);
                     memset(lens + i, lens[i - 1], rep);
                     i += rep;
@@ -254,61 +333,104 @@ int inflate_raw(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *
                     i += rep;
                 }
             }
-            if (i != hlit + hdist || lens[256] == 0) return -1;
-            if (!build_table(lens, static_cast<int>(hlit), 0, kLitBits, sc.lit, kLitCap)) return -1;
-            if (!build_table(lens + hlit, static_cast<int>(hdist), 1, kDistBits, sc.dist, kDistCap)) return -1;
-            lit = sc.lit;
-            dist = sc.dist;
+            if (i != hlit + hdist || lens[256] == 0) return fail();
+            if (!build_table(lens, static_cast<int>(hlit), 0, kLitBits, sc->lit, kLitCap)) return fail();
+            if (!build_table(lens + hlit, static_cast<int>(hdist), 1, kDistBits, sc->dist, kDistCap)) return fail();
+            lit = sc->lit;
+            dist = sc->dist;
         } else {
-            return -1;
+            return fail();
         }
-        // ---- the symbol loop ----
-        for (;;) {
-            if (!b.refill()) return -1;
-            if (o + 3 + 258 + 8 > oend) return 1;  // room for three literals and one longest match plus the 8-byte copy overrun
-            uint32_t e = decode(lit, kLitBits, b);
-            if (e_kind(e) == kLiteral) {  // up to three literals per refill (3 x 15 bits of the 56 available)
+        state = kSymbols;
+    }
+
+    // one trip of the symbol loop: up to three literals, or a match, or the end of the block
+    __attribute__((always_inline)) inline void symbols() {
+        if (!b.refill()) return fail();
+        if (o + 3 + 258 + 8 > oend) {  // room for three literals and one longest match plus the 8-byte copy overrun
+            state = kFull;
+            return;
+        }
+        uint32_t e = decode(lit, kLitBits, b);
+        if (e_kind(e) == kLiteral) {  // up to three literals per refill (3 x 15 bits of the 56 available)
+            *o++ = static_cast<uint8_t>(e_value(e));
+            e = decode(lit, kLitBits, b);
+            if (e_kind(e) == kLiteral) {
                 *o++ = static_cast<uint8_t>(e_value(e));
                 e = decode(lit, kLitBits, b);
                 if (e_kind(e) == kLiteral) {
                     *o++ = static_cast<uint8_t>(e_value(e));
-                    e = decode(lit, kLitBits, b);
-                    if (e_kind(e) == kLiteral) {
-                        *o++ = static_cast<uint8_t>(e_value(e));
-                        continue;
-                    }
+                    return;
                 }
-                if (!b.refill()) return -1;  // up to 45 bits may be gone; a match needs up to 5 + 15 + 13 more
             }
-            if (e_kind(e) == kEndOfBlock) break;
-            if (e_kind(e) != kLength) return -1;
-            const uint32_t len = e_value(e) + b.take(e_extra(e));
-            const uint32_t de = decode(dist, kDistBits, b);
-            if (e_kind(de) != kDistance) return -1;
-            const uint32_t d = e_value(de) + b.take(e_extra(de));
-            if (d > static_cast<size_t>(o - out)) return -1;
-            const uint8_t *from = o - d;
-            uint8_t *const stop = o + len;
-            if (d >= 8) {
-                do {
-                    memcpy(o, from, 8);  // chunks never overlap themselves: d >= 8
-                    o += 8;
-                    from += 8;
-                } while (o < stop);
-            } else {
-                do {
-                    *o++ = *from++;
-                } while (o < stop);
-            }
-            o = stop;
+            if (!b.refill()) return fail();  // up to 45 bits may be gone; a match needs up to 5 + 15 + 13 more
         }
-        if (final) break;
+        if (e_kind(e) == kEndOfBlock) {
+            state = final ? kDone : kHeader;
+            return;
+        }
+        if (e_kind(e) != kLength) return fail();
+        const uint32_t len = e_value(e) + b.take(e_extra(e));
+        const uint32_t de = decode(dist, kDistBits, b);
+        if (e_kind(de) != kDistance) return fail();
+        const uint32_t d = e_value(de) + b.take(e_extra(de));
+        if (d > static_cast<size_t>(o - out)) return fail();
+        const uint8_t *from = o - d;
+        uint8_t *const stop = o + len;
+        if (d >= 8) {
+            do {
+                memcpy(o, from, 8);  // chunks never overlap themselves: d >= 8
+                o += 8;
+                from += 8;
+            } while (o < stop);
+        } else {
+            do {
+                *o++ = *from++;
+            } while (o < stop);
+        }
+        o = stop;
     }
-    // bytes not consumed but sitting in the bit buffer belong to what follows (the Adler-32 trailer)
-    b.in -= b.cnt >> 3;
-    *produced = static_cast<size_t>(o - out);
-    *consumed = static_cast<size_t>(b.in - sc.in.data());
-    return *consumed <= n ? 0 : -1;
+    __attribute__((always_inline)) inline void step() {
+        if (state == kSymbols)
+            symbols();
+        else
+            header();
+    }
+    void fail() { state = kMalformed; }
+
+    // 0 ok, 1 output full (grow and retry), -1 malformed; bytes produced / consumed
+    int finish(size_t *produced, size_t *consumed) {
+        if (state == kFull) return 1;
+        if (state != kDone) return -1;
+        b.in -= b.cnt >> 3;  // bytes not consumed but sitting in the bit buffer belong to what follows (the Adler-32 trailer)
+        *produced = static_cast<size_t>(o - out);
+        *consumed = static_cast<size_t>(b.in - in_base);
+        return *consumed <= n ? 0 : -1;
+    }
+};
+
+// returns 0 ok, 1 output full (grow and retry), -1 malformed
+int inflate_raw(const uint8_t *src, size_t n, uint8_t *out, size_t cap, size_t *produced, size_t *consumed, Scratch &sc) {
+    Stream s;
+    s.begin(src, n, out, cap, sc);
+    while (s.active()) s.step();
+    return s.finish(produced, consumed);
+}
+
+// two streams, step by step in turn (see Stream); rc[0], rc[1] as inflate_raw's
+void inflate_raw_pair(const uint8_t *const src[2], const size_t n[2], uint8_t *const out[2], const size_t cap[2], size_t produced[2],
+                      size_t consumed[2], Scratch *const sc[2], int rc[2]) {
+    Stream a, b;
+    a.begin(src[0], n[0], out[0], cap[0], *sc[0]);
+    b.begin(src[1], n[1], out[1], cap[1], *sc[1]);
+    while (a.active() && b.active()) {
+        a.step();
+        b.step();
+    }
+    while (a.active()) a.step();
+    while (b.active()) b.step();
+    rc[0] = a.finish(&produced[0], &consumed[0]);
+    rc[1] = b.finish(&produced[1], &consumed[1]);
 }
 
 }  // namespace
@@ -331,9 +453,48 @@ bool fast_inflate_zlib(const uint8_t *in, size_t n, std::vector<uint8_t> *out, s
         if (consumed + 4 > n - 2) return false;
         const uint8_t *t = in + 2 + consumed;
         const uint32_t want = (static_cast<uint32_t>(t[0]) << 24) | (static_cast<uint32_t>(t[1]) << 16) | (static_cast<uint32_t>(t[2]) << 8) | t[3];
-        if (static_cast<uint32_t>(adler32(adler32(0L, Z_NULL, 0), out->data(), static_cast<uInt>(produced))) != want) return false;
+        if (adler32_fast(out->data(), produced) != want) return false;
         *len = produced;
         return true;
+    }
+}
+
+// Two streams at once (both must be well-formed zlib streams for the fast path; whichever is declined is reported per stream).
+void fast_inflate_zlib_pair(const uint8_t *const in[2], const size_t n[2], std::vector<uint8_t> *const out[2], size_t len[2], bool ok[2]) {
+    thread_local Scratch sc0, sc1;
+    Scratch *const scs[2] = {&sc0, &sc1};
+    bool head_ok[2];
+    for (int k = 0; k < 2; ++k) {
+        ok[k] = false;
+        head_ok[k] = false;
+        if (n[k] < 6) continue;
+        const uint32_t cmf = in[k][0], flg = in[k][1];
+        if ((cmf & 15u) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20u)) continue;
+        head_ok[k] = true;
+        if (out[k]->size() < n[k] * 4 + (1 << 16)) out[k]->resize(n[k] * 4 + (1 << 16));
+    }
+    if (!(head_ok[0] && head_ok[1])) {  // nothing to pair: each through the single-stream decoder
+        for (int k = 0; k < 2; ++k) ok[k] = head_ok[k] && fast_inflate_zlib(in[k], n[k], out[k], &len[k]);
+        return;
+    }
+    const uint8_t *const src[2] = {in[0] + 2, in[1] + 2};
+    const size_t sn[2] = {n[0] - 2, n[1] - 2};
+    uint8_t *const dst[2] = {out[0]->data(), out[1]->data()};
+    const size_t cap[2] = {out[0]->size() - 8, out[1]->size() - 8};
+    size_t produced[2] = {0, 0}, consumed[2] = {0, 0};
+    int rc[2];
+    inflate_raw_pair(src, sn, dst, cap, produced, consumed, scs, rc);
+    for (int k = 0; k < 2; ++k) {
+        if (rc[k] == 1) {  // output did not fit (rare: > 4x + 64 KB): the single-stream decoder grows and retries
+            ok[k] = fast_inflate_zlib(in[k], n[k], out[k], &len[k]);
+            continue;
+        }
+        if (rc[k] < 0 || consumed[k] + 4 > sn[k]) continue;
+        const uint8_t *t = src[k] + consumed[k];
+        const uint32_t want = (static_cast<uint32_t>(t[0]) << 24) | (static_cast<uint32_t>(t[1]) << 16) | (static_cast<uint32_t>(t[2]) << 8) | t[3];
+        if (adler32_fast(dst[k], produced[k]) != want) continue;
+        len[k] = produced[k];
+        ok[k] = true;
     }
 }
 

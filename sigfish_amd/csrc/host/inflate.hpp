@@ -17,4 +17,8 @@ namespace sfa {
 // Returns false on any malformed / unsupported input (the output is then unspecified).
 bool fast_inflate_zlib(const uint8_t *in, size_t n, std::vector<uint8_t> *out, size_t *len);
 
+// The same for TWO streams decoded side by side by one thread (their symbol loops take turns: two dependence chains keep a
+// core busier than one); ok[k] false where stream k was declined, exactly as the single-stream call would.
+void fast_inflate_zlib_pair(const uint8_t *const in[2], const size_t n[2], std::vector<uint8_t> *const out[2], size_t len[2], bool ok[2]);
+
 }  // namespace sfa

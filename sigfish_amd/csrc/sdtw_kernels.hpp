@@ -409,7 +409,14 @@ __device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev,
     int sup = 0;
     if (TRACK) sup = xc.shift(static_cast<int>(s[R - 1]));
     if (STD) {
-        if (t == 0) xc.template set_boundary<TRACK>(lane0, INFINITY);  // from column 1 on, row 0 only continues from its left neighbour
+        // from column 1 on, row 0 only continues from its left neighbour.  Cost-only fill: t is wave-uniform, the boundary word is
+        // rewritten once (a scalar test per step).  With tracking t is per lane (pass 2: every read has its own step), where the
+        // same thing as a branch in the step cost the 16-row pass 2 over a hundred scratch reloads per four steps (r03: 19 GB of
+        // FETCH_SIZE per --dtw-std launch): a select on the value instead, the word keeps its 0.
+        if (TRACK)
+            up = (lane0 && t > 0) ? INFINITY : up;
+        else if (t == 0)
+            xc.template set_boundary<TRACK>(lane0, INFINITY);
     }
     float diag = dprev;
     int sdiag = sdprev;

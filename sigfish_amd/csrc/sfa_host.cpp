@@ -296,4 +296,29 @@ int64_t sfa_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap) 
     return static_cast<int64_t>(len);
 }
 
+int sfa_inflate_zlib_pair(const uint8_t *in0, size_t n0, const uint8_t *in1, size_t n1, uint8_t *out0, size_t cap0, uint8_t *out1,
+                          size_t cap1, int64_t len[2]) {
+    if (!in0 || !in1 || !len || (!out0 && cap0) || (!out1 && cap1)) return SFA_EINVAL;
+    thread_local std::vector<uint8_t> b0, b1;
+    const uint8_t *const in[2] = {in0, in1};
+    const size_t n[2] = {n0, n1};
+    std::vector<uint8_t> *const bufs[2] = {&b0, &b1};
+    uint8_t *const outs[2] = {out0, out1};
+    const size_t caps[2] = {cap0, cap1};
+    size_t got[2] = {0, 0};
+    bool ok[2];
+    sfa::fast_inflate_zlib_pair(in, n, bufs, got, ok);
+    for (int k = 0; k < 2; ++k) {
+        if (!ok[k]) {
+            len[k] = SFA_EINVAL;
+        } else if (got[k] > caps[k]) {
+            len[k] = SFA_ERANGE;
+        } else {
+            if (got[k]) memcpy(outs[k], bufs[k]->data(), got[k]);
+            len[k] = static_cast<int64_t>(got[k]);
+        }
+    }
+    return SFA_OK;
+}
+
 }  // extern "C"

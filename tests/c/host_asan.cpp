@@ -86,6 +86,40 @@ int main(int argc, char **argv) {
         if (rc < 0) ++rejected;
         sfa_blow5_close(f);
     }
+    // the reader's threads inflate records two at a time (sfa_inflate_zlib_pair): pairs of the file's own records, one or both
+    // damaged (flipped bits, truncation, random tails), into generous and into too-small buffers
+    int pair_ok = 0, pair_declined = 0;
+    {
+        std::vector<std::vector<unsigned char>> recs;
+        uint32_t hsize;
+        memcpy(&hsize, src.data() + 64, 4);
+        size_t p = 68 + hsize;
+        while (p + 8 <= src.size() && memcmp(src.data() + p, "5WOLB", 5) != 0) {
+            uint64_t sz;
+            memcpy(&sz, src.data() + p, 8);
+            if (sz > src.size() - p - 8) break;
+            recs.emplace_back(src.begin() + p + 8, src.begin() + p + 8 + sz);
+            p += 8 + sz;
+        }
+        if (recs.size() < 2) return 9;
+        std::vector<unsigned char> o0(1 << 16), o1(1 << 16);
+        for (int it = 0; it < 3000; ++it) {
+            std::vector<unsigned char> a = recs[rng() % recs.size()], b = recs[rng() % recs.size()];
+            for (std::vector<unsigned char> *v : {&a, &b}) {
+                switch (rng() % 5) {
+                    case 0: (*v)[rng() % v->size()] ^= static_cast<unsigned char>(1u << (rng() % 8)); break;
+                    case 1: v->resize(rng() % v->size() + 1); break;
+                    case 2: for (int k = 0; k < 9; ++k) v->push_back(static_cast<unsigned char>(rng())); break;
+                    default: break;  // intact
+                }
+            }
+            const size_t c0 = (it % 7 == 0) ? 100 : o0.size(), c1 = (it % 11 == 0) ? 0 : o1.size();
+            int64_t len[2];
+            if (sfa_inflate_zlib_pair(a.data(), a.size(), b.data(), b.size(), o0.data(), c0, o1.data(), c1, len) != 0) return 10;
+            for (int k = 0; k < 2; ++k) (len[k] >= 0 ? pair_ok : pair_declined) += 1;
+        }
+        if (pair_ok < 2000 || pair_declined < 500) return 11;
+    }
     std::vector<int64_t> qo(5001, 0);
     for (int i = 0; i < 5000; ++i) qo[i + 1] = qo[i] + (rng() % 9 == 0 ? rng() % 2049 : 250);
     const int32_t jl[2] = {29898, 29898};
@@ -93,6 +127,7 @@ int main(int argc, char **argv) {
     sfa_plan_info_t info;
     for (int w : {0, 1, 2, 4})
         if (sfa_plan_batch(qo.data(), 5000, jl, 2, 0, 0, w, slot.data(), &info) != 0) return 7;
-    printf("%ld reads, %ld events, %d of 300 corrupt files rejected, %d quads\n", reads, events, rejected, info.n_quads);
+    printf("%ld reads, %ld events, %d of 300 corrupt files rejected, %d / %d paired streams inflated / declined, %d quads\n", reads, events, rejected,
+           pair_ok, pair_declined, info.n_quads);
     return (reads > 0 && rejected > 250) ? 0 : 8;
 }
