@@ -6,6 +6,7 @@
 
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <immintrin.h>
 #include <zlib.h>
 
@@ -152,7 +153,35 @@ bool decode_svb_zd(const uint8_t *p, size_t nbytes, std::vector<int16_t> *out) {
 }
 }  // namespace
 
+void Blow5Reader::stop_prefault() {
+    if (prefault_.joinable()) {
+        prefault_quit_ = true;
+        prefault_.join();
+    }
+    prefault_quit_ = false;
+}
+
+void Blow5Reader::start_prefault(size_t window) {
+    stop_prefault();
+    if (!map_) return;
+    consumed_ = map_pos_;
+    const uint8_t *base = map_;
+    const size_t size = map_size_, start = map_pos_;
+    prefault_ = std::thread([this, base, size, start, window] {
+        unsigned sink = 0;
+        for (size_t pos = start & ~size_t(4095); pos < size && !prefault_quit_; pos += 4096) {
+            while (pos > consumed_.load(std::memory_order_relaxed) + window && !prefault_quit_) {
+                struct timespec ts = {0, 200000};  // 0.2 ms: far ahead already
+                nanosleep(&ts, nullptr);
+            }
+            sink += *reinterpret_cast<const volatile uint8_t *>(base + pos);
+        }
+        (void)sink;
+    });
+}
+
 void Blow5Reader::close() {
+    stop_prefault();
     if (map_) munmap(const_cast<uint8_t *>(map_), map_size_);
     map_ = nullptr;
     map_size_ = map_pos_ = 0;
@@ -249,6 +278,7 @@ int Blow5Reader::next_view(const uint8_t **mem, size_t *size) {
     *mem = map_ + map_pos_ + 8;
     *size = static_cast<size_t>(sz);
     map_pos_ += 8 + static_cast<size_t>(sz);
+    consumed_.store(map_pos_, std::memory_order_relaxed);
     return 1;
 }
 

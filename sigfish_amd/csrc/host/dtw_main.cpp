@@ -97,7 +97,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [4 for compressed files on up to 2 GPUs]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [0]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -309,6 +309,7 @@ static int dtw_run(int argc, char **argv) {
     double ti = realtime();
     sfa::Blow5Reader reader;
     if (!reader.open(blow5)) die(reader.error());
+    reader.start_prefault();  // a helper thread takes the page faults of the mapped file ahead of the batch loop (blow5.hpp)
     t_init[0] = realtime() - ti;
     ti = realtime();
     if (const char *exp = reader.attr("experiment_type")) {
@@ -428,14 +429,14 @@ static int dtw_run(int argc, char **argv) {
     // LDS -- and the host route is the better one at the default -K 4096.  What the device route buys is independence from the
     // host: a node's cores do not grow with its GPUs, so it is the default from three devices on.
     const bool gpu_parse = gpu_events && (o.gpu_parse < 0 ? o.devices.size() > 2 : o.gpu_parse == 1);
-    // ... or some of them (round 3): the two routes load DIFFERENT resources -- the host route's inflate keeps the -t threads busy
-    // (27 us per record and core) while the device idles half of the time, the device route costs the host a memcpy and the
-    // device a decode it has room for.  Every Nth batch on the device route, the others on the host route: with N = 4 a group of
-    // four 4 096-read batches costs the main thread 7 + 7 + 7 + 1 ms and the device 4 x 4.2 + 4 ms -- both busy, neither waiting
-    // (profiles/r03_logs/e2e_hybrid_parse.log).  Only where there is something to inflate (zlib records) and host-route is the
-    // choice anyway; rows and text are the same whichever route a batch takes (all CLI goldens run host, device and hybrid).
-    const int hybrid_every = (!gpu_events || gpu_parse || o.gpu_parse == 0 || prf) ? 0
-                             : (o.hybrid_every >= 0 ? o.hybrid_every : ((reader.records_zlib() && o.devices.size() <= 2) ? 4 : 0));
+    // ... or some of them (round 3, --hybrid-parse N): every Nth batch on the device route, the others on the host route -- the two
+    // routes load different resources.  While the host stage was the limit (27 us of inflate per record and core) that paid:
+    // whole process on a compressed 400 000-read file 0.32 M reads/s host route, 0.36 / 0.37 / 0.39 M with every 4th / 3rd / 2nd
+    // batch on the device (profiles/r03_logs/e2e_bench_before_paired_inflate_hybrid4.json and its neighbours).  Since the host
+    // threads inflate two records side by side and a helper takes the mapping's page faults, the host stage (0.44 s for that
+    // file) is level with the device's stages (0.88 s over two contexts), and handing batches to the device only moves the limit
+    // there: 0.43 M host route, 0.39-0.42 M with every 6th / 4th batch (e2e_prefault_and_hybrid_400k.log).  Off unless asked for.
+    const int hybrid_every = (!gpu_events || gpu_parse || o.gpu_parse == 0 || prf) ? 0 : (o.hybrid_every >= 0 ? o.hybrid_every : 0);
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);
