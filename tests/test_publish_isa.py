@@ -71,3 +71,16 @@ def test_valu_per_cell_of_the_headline_loop_is_counted_from_the_build(funcs):
     # three arithmetic instructions per cell + the window minimum and loop overhead: 3.0 .. 3.2
     assert 3.0 <= st["valu_per_cell_min"] <= st["valu_per_cell"] <= st["valu_per_cell_max"] <= 3.2, st
     assert st["median_loop"]["vmem"] <= 2 and st["median_loop"]["lds"] == 2 * st["median_loop"]["cells"] // 16
+
+
+def test_pass_2_of_the_fused_launch_keeps_its_step_loops_free_of_scratch(funcs):
+    """A spilled register inside the step loop is memory traffic per step: the first --dtw-std build of the fused launch fetched
+    19 GB and wrote 2.5 GB per launch that way (124 scratch reloads per four steps; found by the PMC pass).
+    Pass 2 may spill around its loops (it is a function call with a 128-VGPR budget), not in them."""
+    per = I.scratch_in_hot_loops(funcs, r"fused_trace_dispatch")
+    assert len(per) >= 6  # MAXR 4 / 8 / 16, subsequence and std_dtw
+    assert all(v == (0, 0) for v in per.values()), per
+    # ... and the fill kernels of the fused launches not at all
+    for name, ins in funcs.items():
+        if re.search(r"sdtw_fill_kernelILi\d+ELb0ELb[01]ELb0ELb1ELb1E", name):
+            assert not any(i.startswith("scratch_") for i, _ in ins), name

@@ -304,6 +304,25 @@ def fill_loop_stats(funcs, pattern, min_cells=64):
     return best
 
 
+def scratch_in_hot_loops(funcs, pattern, min_valu=300):
+    """(scratch loads, scratch stores) inside the big loops (>= min_valu VALU instructions per trip: the unrolled step loops) of
+    the functions matching `pattern` -- a spill there is HBM traffic per step (r03: 19 GB per --dtw-std launch)"""
+    out = {}
+    for name, ins in funcs.items():
+        if not re.search(pattern, name):
+            continue
+        worst = (0, 0)
+        for s, e in loops(ins):
+            ops = [_opcode(i) for i, _ in ins[s:e + 1]]
+            if sum(1 for o in ops if _classify(o) == "valu") < min_valu:
+                continue
+            sl, ss = sum(o.startswith("scratch_load") for o in ops), sum(o.startswith("scratch_store") for o in ops)
+            if sl + ss > sum(worst):
+                worst = (sl, ss)
+        out[name] = worst
+    return out
+
+
 def main(argv):
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     so = os.path.join(here, "sigfish_amd", "lib", "libsigfish_amd.so")
@@ -321,6 +340,7 @@ def main(argv):
     stats = {"kernels_checked": seen, "violations": bad,
              "headline_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb0ELb1ELb1E"),
              "std_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb1ELb0ELb1ELb1E"),
+             "scratch_in_pass2_loops_of_the_fused_launch": scratch_in_hot_loops(funcs, r"fused_trace_dispatch"),
              "fill32": fill_loop_stats(funcs, r"sdtw_fill_kernelILi32ELb0ELb0ELb0ELb0ELb0E", min_cells=128)}  # (its 32-row loops only)
     text = json.dumps(stats, indent=1)
     if out:
