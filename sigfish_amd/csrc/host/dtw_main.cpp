@@ -202,9 +202,16 @@ class WorkerPool {
 
 static int dtw_run(int argc, char **argv);
 
+static double g_t0 = 0;
+static int g_verbosity = 0;
+
 int dtw_main(int argc, char **argv) {
     try {
-        return dtw_run(argc, argv);
+        const int rc = dtw_run(argc, argv);
+        // (--verbose 4: where a short run's tail goes -- contexts, page-locked buffers, the mapped file and the slots have been
+        // released by now; what follows is the runtime's own exit)
+        if (g_verbosity >= 4) fprintf(stderr, "[dtw_main::%.3f] device contexts, staging buffers and the file mapping released\n", realtime() - g_t0);
+        return rc;
     } catch (const Fatal &e) {  // every helper thread has been joined by the unwinding (see Fatal)
         fflush(stdout);
         fprintf(stderr, "[sigfish-amd] ERROR: %s\n", e.what());
@@ -214,6 +221,7 @@ int dtw_main(int argc, char **argv) {
 
 static int dtw_run(int argc, char **argv) {
     const double t0 = realtime();
+    g_t0 = t0;
     static option lo[] = {{"threads", required_argument, 0, 't'},   {"batchsize", required_argument, 0, 'K'},
                           {"max-bytes", required_argument, 0, 'B'}, {"verbose", required_argument, 0, 'v'},
                           {"help", no_argument, 0, 'h'},            {"version", no_argument, 0, 'V'},
@@ -747,6 +755,7 @@ static int dtw_run(int argc, char **argv) {
         fprintf(stderr, "[dtw_main] Data output time: %.3f sec\n", t_out);
     }
     if (o.verbosity >= 4) fprintf(stderr, "[dtw_main::%.3f] all output written; releasing the device\n", realtime() - t0);
+    g_verbosity = o.verbosity;
     return 0;
 }
 
