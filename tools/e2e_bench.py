@@ -24,6 +24,13 @@ BIN = os.path.join(ROOT, "sigfish_amd", "bin", "sigfish-amd")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+# Every timed run is its own process; the driver is still tearing down the previous one's device contexts for a moment after it
+# exits, and a process started right then waits for that inside its own start-up (measured: 2 contexts in 0.20-0.26 s back to
+# back, 0.11-0.14 s after a second's pause; profiles/r03_logs/rejected_cli_async_init_run_ahead_and_fast_exit.log).  The pause is
+# not timed: the figure is the wall time of ONE command, as a user would run it.
+PAUSE_S = 1.0
+
+
 def _scratch_dir(need_bytes):
     """Where the generated files go: memory-backed /dev/shm when it has room (the leg measures the pipeline, not the box's
     disk), else the ordinary temporary directory."""
@@ -53,6 +60,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
         d, where = _scratch_dir(reads * 10_000)  # ~9.6 KB per read uncompressed
     out = {"unit": "reads/s", "reads": 0, "host_threads": threads, "files_in": where,
            "page_cache": "warm: every generated file is synced and read once before its first timed run",
+           "pause_before_each_run_s": PAUSE_S,
            "what": "raw BLOW5 -> PAF through `sigfish-amd dtw` (process start to exit), reference's DNA fixture replicated, nCoV reference"}
     try:
         lv = np.fromfile(os.path.join(GOLD, "models", "syn6.f32"), np.float32)
@@ -71,6 +79,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
             _warm(path)
             for k in ks:
                 paf = os.path.join(d, "out.paf")
+                time.sleep(PAUSE_S)
                 t0 = time.perf_counter()
                 with open(paf, "wb") as fo:
                     r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", str(k), "-B", "2G", "--verbose", "0", *extra,
@@ -91,6 +100,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=()):
                 out["reads"] = n
                 out[f"{kind}_K{k}"] = round(n / dt, 1)
             if kind == "compressed":  # the same file with the records decompressed and parsed on the device (sfa_align_blow5)
+                time.sleep(PAUSE_S)
                 t0 = time.perf_counter()
                 with open(os.path.join(d, "out.paf"), "wb") as fo:
                     r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", "8192", "-B", "2G", "--verbose", "0",
