@@ -725,7 +725,16 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     if ((rc = c->d_started.reserve(64))) return rc;
     da.started = c->d_started.as<unsigned>();
     da.err = c->d_badcount.as<unsigned>() + 4;
-    da.spin_limit = c->opt_spin_limit_ms * 100000;  // 100 MHz ticks
+    {   // a pass-2 wave legitimately waits for as long as one fill task of its quad runs: never less than ~5x that (1 us per
+        // column of the longest chunk, against 0.2 measured), however small the option -- a 250 Mb strand is minutes, not a hang
+        int64_t longest = 0;
+        for (int32_t ch = 0; ch < n_chunks; ++ch) {
+            int64_t cols = 0;
+            for (int32_t j = plan.chunk_begin[ch]; j < plan.chunk_begin[ch + 1] && j < n_jobs; ++j) cols += c->h_job_len[j];
+            longest = std::max(longest, cols);
+        }
+        da.spin_limit = std::max<int64_t>(c->opt_spin_limit_ms, longest / 1000) * 100000;  // 100 MHz ticks
+    }
     da.debug_drop_quad = static_cast<int32_t>(c->opt_debug_drop_quad);
 #ifdef SFA_TASK_TIMES
     if ((rc = c->d_times.reserve(24 * static_cast<size_t>(std::max(da.n_tasks, 1))))) return rc;
