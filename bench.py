@@ -53,6 +53,57 @@ def host_cores():
     return n
 
 
+def quote_profile(profiles_dir, workload, reads, opts, build_id):
+    """(traffic bytes per fill launch | None, where that came from / why not, VALU issue figures | None) from the committed PMC
+    passes: profiles/<tag>_meta.json names build id, workload, reads per step and options of the profile <tag>; only a profile
+    of THIS build on THIS workload, batch size and options is quoted.  Tags are compared in natural order (r03_v10 after
+    r03_v9, r10 after r9), never by modification time -- a checkout does not keep it."""
+    import glob
+    traffic, traffic_src, issue = None, None, None
+
+    def natural(path):
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
+    metas = []
+    for mp in sorted(glob.glob(os.path.join(profiles_dir, "r*_meta.json")), key=natural):
+        try:
+            m = json.load(open(mp))
+        except ValueError:
+            continue
+        if m.get("workload") == workload and int(m.get("reads", -1)) == reads and sorted(m.get("opts", [])) == sorted(opts):
+            metas.append((mp, m))
+    same = [(mp, m) for mp, m in metas if m.get("build_id") == build_id]
+    if not metas:
+        return None, f"not profiled: no profiles/*_meta.json for workload {workload}, {reads} reads, options {sorted(opts)}", None
+    if not same:
+        mp, m = metas[-1]
+        return None, f"stale: {os.path.basename(mp)} was taken on build {m.get('build_id')}, this library is build {build_id}", None
+    mp, m = same[-1]
+    tag = os.path.basename(mp)[:-len("_meta.json")]
+    pmc = os.path.join(profiles_dir, tag + "_pmc_summary.csv")
+    if not os.path.exists(pmc):
+        return None, f"profiles/{tag}_meta.json has no PMC summary next to it", None
+    vals, durs = {}, {}
+    for line in open(pmc).read().splitlines()[1:]:
+        kname, counter, _, mean, dur = line.rsplit(",", 4)
+        if "sdtw_fill_kernel" in kname:
+            vals[counter] = vals.get(counter, 0.0) + float(mean)
+            durs[counter] = float(dur)
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB -> bytes (MI355X_MICROARCH.md section HBM)
+        traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+        traffic_src = f"profiles/{tag}_pmc_summary.csv (separate rocprofv3 --pmc passes of build {m['build_id']}, same workload, batch size and options)"
+    if "SQ_INSTS_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
+        # wave-instructions per cycle and SIMD over the profiled launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs), against
+        # what this opcode mix reaches in isolation (tools/valu_ceiling.hip: 0.455 -- v_min3 is half rate), and the clock
+        # the chip sustained meanwhile (power-limited; nominal 2.4 GHz)
+        cycles = vals["GRBM_GUI_ACTIVE"] / 8
+        rate = vals["SQ_INSTS_VALU"] / 1024 / cycles
+        issue = {"issue_rate": round(rate, 4), "issue_ceiling": 0.455, "attainable_frac": round(rate / 0.455, 4),
+                 "sustained_clock_ghz": round(cycles / (durs["GRBM_GUI_ACTIVE"] * 1e-3) / 1e9, 3),
+                 "source": f"profiles/{tag}_pmc_summary.csv (SQ_INSTS_VALU, GRBM_GUI_ACTIVE); ceiling: tools/valu_ceiling.hip"}
+    return traffic, traffic_src, issue
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,52 +265,10 @@ def main():
         ops_src = f"sigfish_amd/lib/libsigfish_amd.isa.json: median steady-state loop of {isa_key} ({isa[isa_key]['kernel']})"
     except (OSError, KeyError, TypeError, ValueError):
         pass
-    # HBM bytes per fill launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB -> bytes;
-    # MI355X_MICROARCH.md section HBM).  Counters cannot be collected inside this run, so the figure is only quoted when a
-    # profile under profiles/ was taken on THIS build of the library, on this workload, batch size and options
-    # (profiles/<tag>_meta.json, written by tools/profile_round.sh); otherwise `traffic` is null and `traffic_source` says why.
-    traffic, traffic_src, issue = None, None, None
-    import glob
-
-    def natural(path):
-        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
-    metas = []
-    for mp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_meta.json")), key=natural):
-        try:
-            m = json.load(open(mp))
-        except ValueError:
-            continue
-        if m.get("workload") == args.workload and int(m.get("reads", -1)) == n and sorted(m.get("opts", [])) == sorted(args.opt):
-            metas.append((mp, m))
-    same = [(mp, m) for mp, m in metas if m.get("build_id") == S.build_id()]
-    if not metas:
-        traffic_src = f"not profiled: no profiles/*_meta.json for workload {args.workload}, {n} reads, options {sorted(args.opt)}"
-    elif not same:
-        mp, m = metas[-1]
-        traffic_src = f"stale: {os.path.basename(mp)} was taken on build {m.get('build_id')}, this library is build {S.build_id()}"
-    else:
-        mp, m = same[-1]
-        tag = os.path.basename(mp)[:-len("_meta.json")]
-        pmc = os.path.join(ROOT, "profiles", tag + "_pmc_summary.csv")
-        if os.path.exists(pmc):
-            vals, durs = {}, {}
-            for line in open(pmc).read().splitlines()[1:]:
-                kname, counter, _, mean, dur = line.rsplit(",", 4)
-                if "sdtw_fill_kernel" in kname:
-                    vals[counter] = vals.get(counter, 0.0) + float(mean)
-                    durs[counter] = float(dur)
-            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-                traffic = round((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
-                traffic_src = f"profiles/{tag}_pmc_summary.csv (separate rocprofv3 --pmc passes of build {m['build_id']}, same workload, batch size and options)"
-            if "SQ_INSTS_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
-                # wave-instructions per cycle and SIMD over the profiled launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs), against
-                # what this opcode mix reaches in isolation (tools/valu_ceiling.hip: 0.455 -- v_min3 is half rate), and the clock
-                # the chip sustained meanwhile (power-limited; nominal 2.4 GHz)
-                cycles = vals["GRBM_GUI_ACTIVE"] / 8
-                rate = vals["SQ_INSTS_VALU"] / 1024 / cycles
-                issue = {"issue_rate": round(rate, 4), "issue_ceiling": 0.455, "attainable_frac": round(rate / 0.455, 4),
-                         "sustained_clock_ghz": round(cycles / (durs["GRBM_GUI_ACTIVE"] * 1e-3) / 1e9, 3),
-                         "source": f"profiles/{tag}_pmc_summary.csv (SQ_INSTS_VALU, GRBM_GUI_ACTIVE); ceiling: tools/valu_ceiling.hip"}
+    # HBM bytes per fill launch and the measured VALU issue rate: counters cannot be collected inside this run, so they are
+    # quoted from the committed PMC passes of THIS build on this workload, batch size and options (quote_profile); otherwise
+    # `traffic` is null and `traffic_source` says why.
+    traffic, traffic_src, issue = quote_profile(os.path.join(ROOT, "profiles"), args.workload, n, args.opt, S.build_id())
     out = {
         "metric": ("reads/s (sDTW alignment stage: nCoV-2019 R9 DNA, -q 250, both strands)" if args.workload == "ncov_r9_dna_q250"
                    else f"reads/s (sDTW alignment stage: {args.workload})"),
