@@ -625,13 +625,21 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     };
 
     // one step; t = 0 (std_dtw's special column of row 0) can only fall into the first four steps of the sweep (t_begin is in
-    // (-4, 0]): every later step is compiled without the test (dp_step: T0).  The tracking fill keeps per-lane semantics.
-    auto step = [&](const float yv, const int u) {
-        if (STD && !TRACK && e >= kStepsPerLoad)
-            dp_step<R, TRACK, STD, int, false>(cv, sv, dprev, sdprev, x, yv, t_begin + e + u, lane0, xc);
-        else
-            dp_step<R, TRACK, STD, int, true>(cv, sv, dprev, sdprev, x, yv, t_begin + e + u, lane0, xc);
-    };
+    // (-4, 0]): every later step of the cost-only std_dtw fill is compiled without the test (dp_step: T0).  A macro, not a lambda:
+    // wrapped in a lambda the SUBSEQUENCE fill of the fused launch came out with 564 bytes of scratch and accesses to it in the
+    // kernel body (3 GB fetched + 2.6 GB written per headline launch, 27 + 15 GB per sequin launch; caught by
+    // tests/test_publish_isa.py and the PMC pass) although its code is textually the plain call.
+#define SFA_DP_STEP(YV, U)                                                                                                   \
+    do {                                                                                                                     \
+        if constexpr (STD && !TRACK) {                                                                                       \
+            if (e >= kStepsPerLoad)                                                                                          \
+                dp_step<R, TRACK, STD, int, false>(cv, sv, dprev, sdprev, x, (YV), t_begin + e + (U), lane0, xc);            \
+            else                                                                                                             \
+                dp_step<R, TRACK, STD, int, true>(cv, sv, dprev, sdprev, x, (YV), t_begin + e + (U), lane0, xc);             \
+        } else {                                                                                                             \
+            dp_step<R, TRACK, STD, int>(cv, sv, dprev, sdprev, x, (YV), t_begin + e + (U), lane0, xc);                       \
+        }                                                                                                                    \
+    } while (0)
     float4u ycur = *reinterpret_cast<const float4u *>(yp);
     // ---- prologue: the last query row has not reached column 0 yet (e_main = roundup4(lq) steps) ----
     const int e_main = lq - t_begin;
@@ -639,7 +647,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         const float4u ynext = *reinterpret_cast<const float4u *>(yp + e + kStepsPerLoad);
         maybe_checkpoint();
 #pragma unroll
-        for (int u = 0; u < kStepsPerLoad; ++u) step(ycur.v[u], u);
+        for (int u = 0; u < kStepsPerLoad; ++u) SFA_DP_STEP(ycur.v[u], u);
         ycur = ynext;
     }
     // ---- main: one last-row cell per step, consumed window by window (src/sigfish.c:891-901).  Blocks of four
@@ -699,7 +707,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             maybe_checkpoint();
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u) {
-                step(yv.v[u], u);
+                SFA_DP_STEP(yv.v[u], u);
                 if (!STD) track();
             }
             e += kStepsPerLoad;
@@ -723,7 +731,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad - 1; ++u) {
                 if (u < rm) {
-                    step(ycur.v[u], u);
+                    SFA_DP_STEP(ycur.v[u], u);
                     if (!STD) track();
                 }
             }
@@ -766,6 +774,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         col += wl;
     }
     pr.remaining -= rlen;
+#undef SFA_DP_STEP
 }
 
 // Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill (worth
