@@ -84,3 +84,14 @@ def test_pass_2_of_the_fused_launch_keeps_its_step_loops_free_of_scratch(funcs):
     for name, ins in funcs.items():
         if re.search(r"sdtw_fill_kernelILi\d+ELb0ELb[01]ELb0ELb1ELb1E", name):
             assert not any(i.startswith("scratch_") for i, _ in ins), name
+
+
+def test_no_cost_only_fill_kernel_touches_scratch_inside_its_step_loops(funcs):
+    """Every cost-only fill kernel (any rows per lane, subsequence / std_dtw / segments / LDS checkpoints / fused): registers may
+    spill around the sweep (the 32-row shapes do, a handful), never inside the unrolled step loops.  A wrapper lambda around
+    the step call was enough to push the headline kernel's state into scratch once (3 GB fetched + 2.6 GB written per launch,
+    27 + 15 GB on the 160-contig workload) with the step time unchanged -- only the counters and this check saw it."""
+    per = I.scratch_in_hot_loops(funcs, r"sdtw_fill_kernelILi\d+ELb0E")
+    assert len(per) >= 20, len(per)
+    bad = {k: v for k, v in per.items() if v != (0, 0)}
+    assert not bad, bad
