@@ -39,7 +39,7 @@ enum {
     SFA_ENODEV = -2,  /* no usable GPU / HIP error */
     SFA_ENOMEM = -3,  /* allocation failed */
     SFA_ERANGE = -4,  /* a size out of range (output buffer too small; sfa_plan_batch: query beyond SFA_MAX_QUERY) */
-    SFA_EKERNEL = -5  /* kernel launch or execution failed */
+    SFA_EKERNEL = -5  /* kernel launch or execution failed (incl. an in-launch hand-over that did not arrive within "spin_limit_ms") */
 };
 
 /* Queries of up to SFA_MAX_QUERY events are held in the registers of one wavefront (two-pass kernels).  Longer ones --
@@ -162,15 +162,23 @@ int sfa_wait_batch(sfa_ctx_t *ctx, sfa_result_t *out, int32_t n_reads);
 
 /* align_db() shaped entry: per-read event tables exactly as db_t holds them (src/sigfish.h:177-178):
  * events[i] -> sfa_event_t array of read i, qstart[i]/qend[i] the window chosen by normalise_single
- * (src/sigfish.c:479-480); reads with n_events[i]==0 are skipped. */
+ * (src/sigfish.c:479-480); reads with n_events[i]==0 are skipped.  The window means are gathered out of the 24-byte event
+ * records into page-locked memory (on a few threads once the batch is large) and uploaded from there. */
 int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int64_t *n_events,
                      const int64_t *qstart, const int64_t *qend, int32_t n_reads, sfa_result_t *out);
 
 /* Tuning knobs (all optional): "single_pass" (0/1: track start columns in one pass instead of fill + trace),
  * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = qlen+16),
- * "lds_ckpt" (1 = default: where every shape of the batch has <= 16 rows per lane and the DTW is the subsequence one, the
- * fill keeps its last two snapshots in LDS and writes one to HBM only when a window becomes a read's best so far, plus a
- * sparse store every 32768 steps for pass 2 to back off to; 0 = every snapshot to HBM), "prio_unit" (columns per step of
+ * "lds_ckpt" (1 = default: where every shape of the batch has <= 16 rows per lane, the fill keeps its last two snapshots in
+ * LDS and writes one to HBM only when a window becomes a read's best so far, plus a sparse store every 32768 steps for pass 2
+ * to back off to -- with --dtw-std, whose single candidate per contig is its last cell, no snapshots at all but the sparse
+ * store; 2 = the same whatever the batch size, and queries of 257..1024 events run as 16-row shapes (32 / 64 lanes per
+ * read) on that route instead of the 32-row kernels; 0 = every snapshot to HBM), "mixed_quads" (1 = default: reads whose
+ * lengths agree modulo the rows per lane of their class share a wavefront; 0 = one length per wavefront),
+ * "spin_limit_ms" (default 20000: the longest a wave of a launch waits for another wave of the same launch -- pass 2 for its
+ * quad's fill tasks, a row strip for the strip above -- before the batch fails with SFA_EKERNEL; never less than about
+ * five times the longest fill task), "debug_drop_quad" / "debug_drop_strip" (test hooks for that bound: the producer
+ * with this index skips its signal; -1 = off), "prio_unit" (columns per step of
  * the fill's longest-remaining-first issue priority in the tail of a launch; 0 = off), "fused_trace" (with "lds_ckpt": 1 =
  * default: pass 2 runs inside the fill launch when the launch has more wave-tasks than the device has wave slots, 2 =
  * always, 0 = always as its own launch), "strip_pipeline" (long queries: 1 = default, the row strips of pass 1 run as one
