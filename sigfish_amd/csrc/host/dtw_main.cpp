@@ -43,6 +43,7 @@ struct Opt {
     std::vector<int> devices{0};  // --device 0,1,...: batches go to the devices in turn
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
     int gpu_parse = -1;        // --gpu-parse / --host-parse: records decompressed and parsed on the GPU / on host threads (-1: by device count)
+    int host_inflate = 0;      // --host-inflate: compressed records are inflated on host threads and parsed + decoded on the GPU
     int hybrid_every = -1;     // --hybrid-parse N: every Nth batch goes to the device as it is in the file, the others through host threads (0: off, -1: auto)
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     const char *model_file = nullptr;
@@ -97,7 +98,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [0]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --host-inflate             inflate the records on host threads, parse and decode them on the GPU [off]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [0]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -117,6 +118,8 @@ struct Read {
     const uint8_t *view = nullptr;     // record bytes inside the mapped file otherwise
     size_t view_size = 0;
     sfa::Blow5Record rec;
+    std::vector<uint8_t> payload;      // --host-inflate: the record's inflated bytes (payload_len of them), parsed on the device
+    size_t payload_len = 0;
     std::vector<sfa_event_t> ev;
     std::vector<float> pa;             // --profile-cpu=yes: picoamps kept between the events and the normalise stage
     int64_t qstart = 0, qend = 0;
@@ -236,7 +239,7 @@ static int dtw_run(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   {"hybrid-parse", required_argument, 0, 18},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   {"hybrid-parse", required_argument, 0, 18},   {"host-inflate", no_argument, 0, 19},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -290,6 +293,7 @@ static int dtw_run(int argc, char **argv) {
             case 14: o.host_events = true; break;
             case 16: o.gpu_parse = 0; break;
             case 17: o.gpu_parse = 1; break;
+            case 19: o.host_inflate = 1; break;
             case 18:
                 o.hybrid_every = atoi(optarg);
                 if (o.hybrid_every < 0 || o.hybrid_every == 1) die("--hybrid-parse takes 0 (off) or an integer >= 2 (use --gpu-parse for every batch)");
@@ -429,6 +433,7 @@ static int dtw_run(int argc, char **argv) {
         int32_t n = 0;
         int64_t bytes = 0;
         bool via_device = false;  // this batch's records go to the device as they are in the file (sfa_align_blow5)
+        bool inflated = false;    // ... after the host threads have inflated them (the device parses fields and decodes signals)
     };
     // events on the GPU unless the RNA auto prefix is asked for (adaptor/poly-A detection stays on the host); for SAM the
     // event tables of the query windows come back from the device with the rows
@@ -448,6 +453,14 @@ static int dtw_run(int argc, char **argv) {
     // file) is level with the device's stages (0.88 s over two contexts), and handing batches to the device only moves the limit
     // there: 0.43 M host route, 0.39-0.42 M with every 6th / 4th batch (e2e_prefault_and_hybrid_400k.log).  Off unless asked for.
     const int hybrid_every = (!gpu_events || gpu_parse || o.gpu_parse == 0 || prf) ? 0 : (o.hybrid_every >= 0 ? o.hybrid_every : 0);
+    // ... or the work of ONE record is split (round 3, --host-inflate): the host threads do the serial bit stream of DEFLATE, two
+    // records side by side per thread, and hand the inflated payloads to the device, which parses the fields and decodes the
+    // StreamVByte signals (sfa_align_blow5 with record_zlib = 0) before it detects events and aligns.  Measured and NOT the
+    // default (profiles/r03_logs/rejected_host_inflate_device_parse_route.log, compressed 400 000-read file, whole process): the
+    // host stage only falls from 0.414 to 0.386 s -- inflating is 15 of the 18 us a record costs a host thread -- while the device
+    // stage grows from 0.77 to 0.84 s (two more host round trips per batch on the record route): 0.36-0.40 M reads/s against
+    // 0.43-0.49 M for the host route and 0.32-0.37 M for the device route.
+    const bool host_inflate = gpu_events && !gpu_parse && !prf && reader.records_zlib() && o.host_inflate == 1;
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);
@@ -468,7 +481,7 @@ static int dtw_run(int argc, char **argv) {
             sl.info.resize(n);
             sl.heads.resize(n);
             if (sam) sl.qev.resize(static_cast<size_t>(n) * o.query);
-            if (n > 0 && sfa_align_blow5(ctx, sl.rec_bytes, sl.rec_off.data(), n, reader.records_zlib(), reader.signal_svb(), o.prefix, o.query,
+            if (n > 0 && sfa_align_blow5(ctx, sl.rec_bytes, sl.rec_off.data(), n, sl.inflated ? 0 : reader.records_zlib(), reader.signal_svb(), o.prefix, o.query,
                                          rows.data(), sl.info.data(), sl.heads.data(), sam ? sl.qev.data() : nullptr) != SFA_OK)
                 die(std::string("alignment failed: ") + sfa_last_error());
         } else if (gpu_events) {
@@ -587,7 +600,8 @@ static int dtw_run(int argc, char **argv) {
         }
         sl.n = n;
         sl.bytes = bytes;
-        sl.via_device = gpu_parse || (hybrid_every > 0 && bi % hybrid_every == hybrid_every - 1);
+        sl.via_device = gpu_parse || host_inflate || (hybrid_every > 0 && bi % hybrid_every == hybrid_every - 1);
+        sl.inflated = host_inflate;
         t_load += realtime() - a;
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
@@ -614,11 +628,31 @@ static int dtw_run(int argc, char **argv) {
                 r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), static_cast<int64_t>(r.rec.raw.size()), pa.data(), o.prefix, o.query,
                                                    o.flag, o.pore_flag, &r.qstart, &r.qend, &r.status);
         };
-        if (sl.via_device) {  // nothing to parse here: the records go to the device as they are
+        if (sl.via_device) {  // nothing to parse here: the records go to the device as they are -- or inflated, two per thread
             double b = realtime();
+            if (sl.inflated) {
+                pool.run((n + 1) / 2, [&](int64_t j) {
+                    const int64_t i0 = 2 * j, i1 = std::min<int64_t>(2 * j + 1, n - 1);
+                    Read &a0 = batch[i0], &a1 = batch[i1];
+                    if (i1 == i0) {
+                        if (!reader.inflate_record(a0.view ? a0.view : a0.mem.data(), a0.view_size, &a0.payload, &a0.payload_len)) bad = 1;
+                        return;
+                    }
+                    const uint8_t *const mem[2] = {a0.view ? a0.view : a0.mem.data(), a1.view ? a1.view : a1.mem.data()};
+                    const size_t size[2] = {a0.view_size, a1.view_size};
+                    std::vector<uint8_t> *const out[2] = {&a0.payload, &a1.payload};
+                    size_t len[2] = {0, 0};
+                    bool ok[2];
+                    reader.inflate_pair(mem, size, out, len, ok);
+                    a0.payload_len = len[0];
+                    a1.payload_len = len[1];
+                    if (!ok[0] || !ok[1]) bad = 1;
+                });
+                if (bad) die("malformed BLOW5: record does not inflate");
+            }
             sl.rec_off.resize(n + 1);
             sl.rec_off[0] = 0;
-            for (int32_t i = 0; i < n; ++i) sl.rec_off[i + 1] = sl.rec_off[i] + static_cast<int64_t>(batch[i].view_size);
+            for (int32_t i = 0; i < n; ++i) sl.rec_off[i + 1] = sl.rec_off[i] + static_cast<int64_t>(sl.inflated ? batch[i].payload_len : batch[i].view_size);
             const size_t need = static_cast<size_t>(sl.rec_off[n]) + 64;
             if (need > sl.rec_cap) {
                 sfa_pinned_free(sl.rec_bytes);
@@ -627,8 +661,8 @@ static int dtw_run(int argc, char **argv) {
                 if (!sl.rec_bytes) die(std::string("cannot allocate the record staging buffer: ") + sfa_last_error());
             }
             pool.run(n, [&](int64_t i) {
-                const uint8_t *src = batch[i].view ? batch[i].view : batch[i].mem.data();
-                memcpy(sl.rec_bytes + sl.rec_off[i], src, batch[i].view_size);
+                const uint8_t *src = sl.inflated ? batch[i].payload.data() : (batch[i].view ? batch[i].view : batch[i].mem.data());
+                memcpy(sl.rec_bytes + sl.rec_off[i], src, static_cast<size_t>(sl.rec_off[i + 1] - sl.rec_off[i]));
             });
             t_parse += realtime() - b;
         } else if (!prf) {  // one fan-out per batch, every read through all its host stages (work_per_single_read, src/sigfish.c:995-1001)

@@ -106,12 +106,14 @@ RANDOM_CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(G
 
 @pytest.mark.parametrize("name", RANDOM_CASES)
 @pytest.mark.parametrize("extra", [[], ["-K", "7"], ["--host-events"], ["--gpu-parse"], ["--gpu-parse", "-K", "7"], ["--host-parse", "-K", "7"],
-                                   ["--hybrid-parse", "2", "-K", "7"], ["--hybrid-parse", "3", "-K", "3"], ["--hybrid-parse", "0", "-K", "7"]])
+                                   ["--hybrid-parse", "2", "-K", "7"], ["--hybrid-parse", "3", "-K", "3"], ["--hybrid-parse", "0", "-K", "7"],
+                                   ["--host-inflate", "-K", "7"], ["--host-inflate", "--hybrid-parse", "2", "-K", "3"]])
 def test_cli_random_signal_goldens(name, extra, models):
     """Synthetic step signals in compressed BLOW5 files (40 reads each) whose PAF / SAM text the compiled reference
     printed (tests/golden/random, oracle/make_golden.py): the command line must print the same, through device-side and
-    host-side event detection, in one batch and in several, with the records parsed on host threads, on the device, or -- the
-    default for compressed files, every fourth batch; here every second / third -- batch by batch on either."""
+    host-side event detection, in one batch and in several, with the records parsed on host threads (--host-parse), on the device
+    (--gpu-parse), batch by batch on either (--hybrid-parse), or inflated on host threads and parsed on the device
+    (--host-inflate)."""
     k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
     cmd = [BIN, "dtw", "--kmer-model", models[int(k)], "--verbose", "0", *args, *extra, os.path.join(GOLD, "data", fasta),
            os.path.join(GOLD, "random", blow5)]
