@@ -10,7 +10,8 @@
 //   * strand flip, ref_st_offset, mapq                               src/sigfish.c:969-983
 //
 // Mapping to the machine (MI355X-first, not a translation of the CPU loops):
-//   * one read occupies ONE DPP ROW (16 lanes) of a wave64; four reads ("a quad", equal query length) ride in
+//   * one read occupies ONE DPP ROW (16 lanes) of a wave64; four reads ("a quad": one length class, lengths equal modulo the
+//     rows per lane so that every read's last query row sits in the same lane and register -- MixedQuad) ride in
 //     a wave.  Lane g of a row owns R consecutive query rows (R = 4/8/16/32 -> queries up to 64/128/256/512
 //     events), kept in VGPRs together with their running cost.  No barriers, no cost matrix.  Queries longer
 //     than 512 events take 32 or 64 lanes per read at R = 32 (two reads / one read per wave, up to 1024 / 2048

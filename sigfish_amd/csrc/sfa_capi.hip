@@ -2,7 +2,7 @@
 //
 // Replaces the reference's accelerator hook align_db() (src/sigfish.c:1003-1015) and its init / teardown slots
 // (src/sigfish.c:200-204, 221-225).  Host work done here: pack the reference event arrays into one padded HBM
-// buffer, group reads into "quads" of equal query length (four reads share a wavefront), pick the
+// buffer, group reads into "quads" (four reads of one length class share a wavefront; sfa_plan.hpp), pick the
 // rows-per-lane class, size the checkpoint interval, launch fill -> finalize -> trace -> finalize, and hand back
 // one row per read in input order.
 // There is NO CPU fallback: every failure is reported through the return code + sfa_last_error().
