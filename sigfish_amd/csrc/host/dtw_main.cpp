@@ -522,7 +522,7 @@ static int dtw_run(int argc, char **argv) {
         const double a = realtime();
         if (o.flag & F_SAM) {
             // the warp path of every winner is rebuilt on the host from its band (sam.hpp), one read per task
-            std::vector<std::string> sam(n);
+            std::vector<std::string> sam_rows(n);
             pool.run(n, [&](int64_t i) {
                 const Read &r = batch[i];
                 const sfa_result_t &row = rows[i];
@@ -540,9 +540,9 @@ static int dtw_run(int argc, char **argv) {
                     len = sfa_sam_row(&buf[0], buf.size(), &row, rid, contigs[row.rid].name.c_str(), ev, qs, qe, y,
                                       ref_len[row.rid], ref_off[row.rid], o.flag);
                 }
-                if (len > 0) sam[i].assign(buf.data(), len);
+                if (len > 0) sam_rows[i].assign(buf.data(), len);
             });
-            for (int32_t i = 0; i < n; ++i) fwrite(sam[i].data(), 1, sam[i].size(), stdout);
+            for (int32_t i = 0; i < n; ++i) fwrite(sam_rows[i].data(), 1, sam_rows[i].size(), stdout);
         } else {
             std::string line(4096, '\0');
             for (int32_t i = 0; i < n; ++i) {  // output_db + aln_to_str, src/sigfish.c:796-826,1051-1086
@@ -683,9 +683,9 @@ static int dtw_run(int argc, char **argv) {
                     const size_t size[2] = {a0.view_size, a1.view_size};
                     sfa::Blow5Record *const rec[2] = {&a0.rec, &a1.rec};
                     std::string e0, e1;
-                    std::string *const err[2] = {&e0, &e1};
+                    std::string *const perr[2] = {&e0, &e1};
                     bool ok[2];
-                    reader.parse_pair(mem, size, rec, err, ok);
+                    reader.parse_pair(mem, size, rec, perr, ok);
                     if (!ok[0] || !ok[1]) bad = 1;
                     for (Read *r : {&a0, &a1}) {
                         r->keep = false;
