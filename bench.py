@@ -257,7 +257,7 @@ def main():
     # VALU instructions per DP cell: counted from the steady-state loop of the kernel this workload runs, in the ISA of the
     # library that is loaded (tools/isa_check.py; the Makefile leaves the figures next to the .so)
     std = bool(flag & S.DTW)
-    isa_key = "std_fill" if std else ("fill32" if qlen > 1024 else "headline_fill")
+    isa_key = "std_fill" if std else ("fill32" if qlen > 256 else "headline_fill")  # (queries beyond 256 events: the 32-row kernels)
     ops_per_cell, ops_src = 49 / 16, "constant 49/16 (no ISA statistics next to the library)"
     try:
         isa = json.load(open(os.path.join(ROOT, "sigfish_amd", "lib", "libsigfish_amd.isa.json")))
