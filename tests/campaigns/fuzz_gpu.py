@@ -71,6 +71,8 @@ def main():
             opts["lds_ckpt"] = 2  # LDS checkpoints whatever the batch size
         if rng.integers(0, 3) == 0:
             opts["prio_unit"] = int(rng.choice([0, 64, 700]))
+        if rng.integers(0, 4) == 0:
+            opts["mixed_quads"] = 0  # one query length per wave (default: lengths equal modulo the rows per lane share waves)
         opts["lane_widening"] = int(rng.choice([0, 1, 1, 2, 4]))  # small batches widen by themselves; pin the other shapes too
         if rng.integers(0, 2):  # column segments (small batches): forced counts and short warm-ups exercise the hand-over check
             opts["column_segments"] = int(rng.choice([1, 2, 3, 8, 16]))
