@@ -106,6 +106,7 @@ typedef struct {
     int64_t blow5_fallbacks; /* batches of this context handed to the host reader because the device declined a record */
     int64_t lds_ckpt;      /* 1: the fill kept its rolling checkpoints in LDS (ckpt_interval is then the sparse HBM store's);
                               2: and pass 2 ran inside the fill launch (fill_ms covers both, trace_ms is 0) */
+    int64_t trace_margin;  /* head start of pass 2 in steps (a whole query + lanes, or less: "adaptive_margin") */
 } sfa_profile_t;
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */
@@ -175,6 +176,9 @@ int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int
  * store; 2 = the same whatever the batch size, and queries of 257..1024 events run as 16-row shapes (32 / 64 lanes per
  * read) on that route instead of the 32-row kernels; 0 = every snapshot to HBM), "mixed_quads" (1 = default: reads whose
  * lengths agree modulo the rows per lane of their class share a wavefront; 0 = one length per wavefront),
+ * "adaptive_margin" (1 = default: where the snapshots of pass 1 are in HBM -- queries beyond 256 events -- pass 2 of a batch
+ * starts as far in front of the winning cell as 99.9 % of the PREVIOUS batch's alignments spanned (+ 1/8 query + lanes + 16)
+ * instead of a whole query length; a read whose path is longer backs off one snapshot; 0 = always a whole query length),
  * "spin_limit_ms" (default 20000: the longest a wave of a launch waits for another wave of the same launch -- pass 2 for its
  * quad's fill tasks, a row strip for the strip above -- before the batch fails with SFA_EKERNEL; never less than about
  * five times the longest fill task), "debug_drop_quad" / "debug_drop_strip" (test hooks for that bound: the producer

@@ -1394,7 +1394,11 @@ struct FinalizeArgs {
     int32_t n_reads, n_chunks;
     int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions;
                    // 3: fused launch -> rows of the reads that are in no quad (skipped), the rest is written by its pass-2 waves
+    // mode 2: how many reference columns the alignments of this batch span, in sixteenths of their query length (32 buckets, the
+    // last one open): what the next batch's pass 2 takes as its head start instead of a whole query length (nullptr: not kept)
+    unsigned *span_hist;
 };
+constexpr int kSpanBuckets = 32;
 
 template <int MAXR, bool STD, bool LCK = false>
 __global__ void __launch_bounds__(256, MAXR <= 16 ? SFA_TRACE_WAVES : 1) sdtw_trace_kernel(const DpArgs a, int32_t *out_st) {
@@ -1615,6 +1619,13 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
         r.pos_st = ((r.strand == '+') ? st : rl - end) + off;  // src/sigfish.c:971-975
         r.pos_end = ((r.strand == '+') ? end : rl - st) + off;
         a.out[i] = r;
+        if (a.span_hist && st >= 0 && end >= st) {
+            const int64_t ql = a.q_off[i + 1] - a.q_off[i];
+            if (ql > 0) {
+                const int64_t b = (static_cast<int64_t>(end - st + 1) * 16) / ql;
+                atomicAdd(a.span_hist + (b < kSpanBuckets - 1 ? static_cast<int>(b) : kSpanBuckets - 1), 1u);
+            }
+        }
         return;
     }
     ResultRow r;

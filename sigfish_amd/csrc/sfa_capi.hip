@@ -216,6 +216,8 @@ struct sfa_ctx {
     int64_t opt_fused_trace = 1;             // 1: with LDS checkpoints, pass 2 rides in the fill launch as trailing tickets (fills the drain)
     int64_t opt_lds_ckpt = 1;                // 1: rolling checkpoints in LDS where the batch's shapes allow (R <= 16, sDTW); 0: all snapshots to HBM
     int64_t opt_prio_unit = 2048;            // longest-remaining-first issue priority of the fill: columns per level, 0 = off
+    int64_t opt_adaptive_margin = 1;         // pass 2's head start follows the spans of the previous batch's alignments (HBM-snapshot route)
+    int32_t span_sixteenths = 0;             // ... in sixteenths of the query length (0: not known yet -> a whole query length)
     int64_t opt_mixed_quads = 1;             // reads of different lengths (equal modulo the rows per lane) may share a wave
     int64_t opt_spin_limit_ms = 20000;       // bound of every in-launch wait (fused pass 2, pipelined strips); beyond it the batch fails with SFA_EKERNEL
     int64_t opt_debug_drop_quad = -1;        // test hook: the fill tasks of this quad never signal completion
@@ -568,6 +570,8 @@ int align_sliced(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         sum.fill_launches += c->prof.fill_launches;
         sum.ckpt_interval = std::max(sum.ckpt_interval, c->prof.ckpt_interval);
         sum.ckpt_bytes = std::max(sum.ckpt_bytes, c->prof.ckpt_bytes);
+        sum.trace_margin = std::max(sum.trace_margin, c->prof.trace_margin);
+        sum.lds_ckpt = std::max(sum.lds_ckpt, c->prof.lds_ckpt);
         sum.n_tasks += c->prof.n_tasks;
         sum.n_chunks = std::max(sum.n_chunks, c->prof.n_chunks);
         sum.non_finite_reads += c->prof.non_finite_reads;
@@ -595,6 +599,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     pp.lds_ckpt = static_cast<int>(c->opt_lds_ckpt);
     pp.std_dtw = (c->flag & SFA_DTW) != 0;
     pp.mixed_quads = c->opt_mixed_quads != 0;
+    pp.span_sixteenths = c->opt_adaptive_margin ? c->span_sixteenths : 0;
     std::vector<int32_t> long_reads;  // queries beyond the wave kernels' 2048 events: row strips, after the rest of the batch
     int64_t long_events = 0, long_max = 0;
     for (int32_t i = 0; i < n; ++i)
@@ -649,7 +654,7 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     if (plan.lds_ckpt && ((rc = c->d_bestrec.reserve(sizeof(float) * sfa::kLdsCkPlanes * 64 * n_part / 4)) || (rc = c->d_beste.reserve(4 * n_part)) ||
                           (rc = c->d_gbest.reserve(4 * static_cast<size_t>(n)))))
         return rc;
-    if ((rc = c->d_bad.reserve(static_cast<size_t>(n))) || (rc = c->d_badcount.reserve(64)) || (rc = c->h_badcount.reserve(64))) return rc;
+    if ((rc = c->d_bad.reserve(static_cast<size_t>(n))) || (rc = c->d_badcount.reserve(256)) || (rc = c->h_badcount.reserve(256))) return rc;
     if (plan.single_pass && (rc = c->d_pst.reserve(4 * n_part))) return rc;
     if (!plan.single_pass && plan.ck_floats > 0 && (rc = c->d_ck.reserve(sizeof(float) * plan.ck_floats))) return rc;
     const int32_t verify_planes = plan.max_R + 1;
@@ -764,12 +769,13 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
     fz.max_query = long_reads.empty() ? 0 : sfa::kMaxQuery;
     fz.n_reads = n;
     fz.n_chunks = n_chunks;
+    fz.span_hist = c->d_badcount.as<unsigned>() + 8;
     const dim3 fgrid((n + 255) / 256), fblock(256);
 
     if (da.prio_unit > 0) HIP_TRY(hipMemsetAsync(c->d_started.p, 0, 4, st));
     HIP_TRY(hipEventRecord(c->ev[0], st));
     // reads with a NaN / inf query value are skipped (the reference aborts on them, see sdtw_screen_kernel)
-    HIP_TRY(hipMemsetAsync(c->d_badcount.p, 0, 32, st));  // word 0: non-finite reads; words 4..6: error words of the in-launch waits
+    HIP_TRY(hipMemsetAsync(c->d_badcount.p, 0, 32 + 4 * sfa::kSpanBuckets, st));  // word 0: non-finite reads; words 4..6: error words of the in-launch waits; words 8..39: span histogram
     hipLaunchKernelGGL(sfa::sdtw_screen_kernel, dim3((n + 3) / 4), dim3(256), 0, st, d_queries, da.q_off, n, c->d_bad.as<uint8_t>(),
                        c->d_badcount.as<unsigned>());
     KERNEL_TRY();
@@ -852,13 +858,14 @@ int align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         HIP_TRY(hipEventRecord(c->ev[5], st));
         if (c->opt_long_overlap) HIP_TRY(hipStreamWaitEvent(st, c->lev[1], 0));
     }
-    HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->h_badcount.p, c->d_badcount.p, 32 + 4 * sfa::kSpanBuckets, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(c->ev[4], st));
 
     c->prof.cells = (plan.query_events + long_events) * c->total_cols;
     c->prof.ckpt_interval = plan.single_pass ? 0 : (plan.ck_shift ? (1 << plan.ck_shift) : 0);
     c->prof.ckpt_bytes = plan.single_pass ? 0 : static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
     c->prof.lds_ckpt = plan.lds_ckpt ? (fused ? 2 : 1) : 0;
+    c->prof.trace_margin = plan.trace_margin;
     c->prof.n_tasks = da.n_tasks;
     c->prof.n_chunks = n_chunks;
     c->prof.n_segments = plan.n_seg;
@@ -925,6 +932,20 @@ int resolve_profile(sfa_ctx *c) {
     c->prof.finalize_ms = t - a - d;
     c->prof.total_ms = t;
     c->prof_pending = false;
+    if (c->h_badcount.p) {  // spans of this batch's alignments -> head start of the next batch's pass 2 (sfa_plan.hpp)
+        const unsigned *h = c->h_badcount.as<unsigned>() + 8;
+        uint64_t total = 0;
+        for (int b = 0; b < sfa::kSpanBuckets; ++b) total += h[b];
+        if (total >= 64) {  // the bucket below which 99.9 % of the alignments lie, one more for safety, never above a whole query
+            uint64_t acc = 0;
+            int b = 0;
+            for (; b < sfa::kSpanBuckets; ++b) {
+                acc += h[b];
+                if (acc * 1000 >= total * 999) break;
+            }
+            c->span_sixteenths = std::min(16, b + 2);
+        }
+    }
     if (c->h_badcount.p) {  // a wave of the batch gave up waiting for another one (bounded_wait_ge): the rows are not to be used
         const unsigned *e = c->h_badcount.as<unsigned>() + 4;
         if (e[0] == sfa::kErrQuadWait)
@@ -1230,6 +1251,9 @@ int sfa_set_option(sfa_ctx_t *c, const char *key, int64_t value) {
     } else if (k == "prio_unit") {
         if (value < 0 || value > (1 << 28)) return fail(SFA_EINVAL, "prio_unit must be 0 (off) .. 2^28");
         c->opt_prio_unit = value;
+    } else if (k == "adaptive_margin") {
+        c->opt_adaptive_margin = value != 0;
+        c->span_sixteenths = 0;
     } else if (k == "mixed_quads") {
         c->opt_mixed_quads = value != 0;
     } else if (k == "spin_limit_ms") {
@@ -1827,6 +1851,8 @@ int sfa_get_profile(sfa_ctx_t *c, sfa_profile_t *p) {
             sum.ckpt_interval = std::max(sum.ckpt_interval, q.ckpt_interval);
             sum.n_chunks = std::max(sum.n_chunks, q.n_chunks);
             sum.n_segments = std::max(sum.n_segments, q.n_segments);
+            sum.lds_ckpt = std::max(sum.lds_ckpt, q.lds_ckpt);
+            sum.trace_margin = std::max(sum.trace_margin, q.trace_margin);
         }
         *p = sum;
         return SFA_OK;

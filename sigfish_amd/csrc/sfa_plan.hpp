@@ -58,6 +58,8 @@ struct PlanParams {
     int64_t ckpt_interval = 0;      // 0 = auto
     int64_t ckpt_budget_bytes = 32ll << 30;
     int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
+    int32_t span_sixteenths = 0;    // > 0 (with trace_margin < 0, snapshots in HBM): the head start of pass 2 is this many sixteenths of the
+                                    // longest query (+ lanes + 16) instead of the whole query -- what the previous batch's alignments spanned
     int64_t lane_widening = 0;      // 0 = auto (by batch size), else 1, 2 or 4
     int64_t widen_below = 5;        // auto: widen (x4) when the batch has fewer than this many waves per SIMD
     int64_t column_segments = 0;    // 0 = auto (small batches of the 64-lane shapes), 1 = off, N = N segments per job
@@ -282,6 +284,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // checkpoint interval
     p.job_ck_off.assign(n_jobs + 1, 0);
     p.trace_margin = static_cast<int32_t>(pp.trace_margin >= 0 ? pp.trace_margin : maxq + p.max_lanes);
+    const bool adapt = pp.trace_margin < 0 && pp.span_sixteenths > 0;  // (applied below, once the checkpoint route is known)
     // LDS checkpoints: every shape of the batch must hold its state in 17 planes (R <= 16), one sweep per (quad, job); the
     // margin is capped so that the snapshot pass 2 wants for a window is one of the last two (LdsCkpt::save):
     // interval (512 / 1024 / 2048 by the longest query) >= window length + margin + 3
@@ -294,6 +297,11 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         if (pp.lds_ckpt < 2 && tasks > 4 * pp.n_sims && tasks <= 6 * pp.n_sims) p.lds_ckpt = false;
     }
     if (p.lds_ckpt && !pp.std_dtw) p.trace_margin = std::min<int32_t>(p.trace_margin, (1 << p.lck_shift) - maxq - 3);
+    // Snapshots in HBM every 512 steps (the 32-row shapes): a head start that turns out too short costs one more attempt from the
+    // snapshot before, so it can follow what alignments actually span (event detection over-segments: ~2/3 of a column per event)
+    // instead of a whole query length.  Not on the LDS route: there a miss falls back to the sparse store or the strand's start.
+    if (adapt && !p.lds_ckpt && !pp.single_pass && !pp.std_dtw)
+        p.trace_margin = std::min<int32_t>(p.trace_margin, static_cast<int32_t>((static_cast<int64_t>(maxq) * pp.span_sixteenths) / 16) + p.max_lanes + 16);
     if (!pp.single_pass && n_quads > 0) {
         int shift = p.lds_ckpt ? 15 : 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length); sparse store: 32768
         if (pp.ckpt_interval > 0) {

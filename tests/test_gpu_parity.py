@@ -563,3 +563,38 @@ def test_no_device_fallback_is_loud():
     ref = _small_ref(np.random.default_rng(0), [50], False)
     with pytest.raises(S.SfaError):
         S.Aligner(ref, 0, device=99)
+
+
+def test_pass_2_head_start_follows_the_previous_batch(oracle):
+    """Queries beyond 256 events keep their snapshots in HBM; there pass 2 starts a whole query length (+ lanes) in front of
+    the winning cell for the first batch of a context and, from then on, as far as 99.9 % of the previous batch's alignments
+    spanned (event detection over-segments: ~2/3 of a column per event) -- rows never change, a path that is longer backs off."""
+    ref, flag, q, q_off, _ = synth.workload("ncov_r9_dna_q500", n_reads=300, seed=5)
+    want = oracle.align_batch(q, q_off, _oracle_ref(oracle, ref), flag, threads=16)
+    with S.Aligner(ref, flag) as al:
+        al.set_option("lane_widening", 1)
+        first = al.align_db(q, q_off)
+        m1 = al.profile()["trace_margin"]
+        second = al.align_db(q, q_off)
+        m2 = al.profile()["trace_margin"]
+        assert m1 == 500 + 16 and 500 * 10 // 16 <= m2 < m1, (m1, m2)
+        assert_rows_equal(first, want)
+        assert_rows_equal(second, want)
+        # reads whose paths are LONGER than the learnt head start (a query stretched over twice as many columns) still come out right
+        rng = np.random.default_rng(9)
+        src = ref.forward[0]
+        qs, offs = [], [0]
+        for _ in range(80):
+            st = int(rng.integers(0, len(src) - 1100))
+            seg = src[st:st + 1000:2] + rng.normal(scale=0.2, size=500).astype(np.float32)  # every second level: ~2 columns per event
+            qs.append(((seg - seg.mean()) / seg.std()).astype(np.float32))
+            offs.append(offs[-1] + 500)
+        q2, off2 = np.concatenate(qs), np.array(offs, np.int64)
+        got = al.align_db(q2, off2)
+        assert al.profile()["trace_margin"] == m2  # planned with what the batch before had shown
+        assert_rows_equal(got, oracle.align_batch(q2, off2, _oracle_ref(oracle, ref), flag, threads=16))
+        al.align_db(q, q_off)
+        assert 500 * 10 // 16 <= al.profile()["trace_margin"] <= 500 + 16  # (whatever those paths spanned: never beyond a whole query)
+        al.set_option("adaptive_margin", 0)
+        al.align_db(q, q_off)
+        assert al.profile()["trace_margin"] == 500 + 16
