@@ -84,6 +84,9 @@ struct StripArgs {
     unsigned *err;
     long long spin_limit;
     int32_t debug_drop_strip;
+#ifdef SFA_TASK_TIMES
+    unsigned long long *task_times;  // measurement builds (tools/strip_task_times.py): [task][3] start, end (100 MHz ticks), SIMD position | strip << 32
+#endif
 };
 
 #ifndef SFA_PIPE_BLOCK
@@ -556,7 +559,16 @@ __global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs
     Exchange xc;
     xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
     const StripRead rd = strip_read(a, li);
+#ifdef SFA_TASK_TIMES
+    if (a.task_times && lane == 0) a.task_times[3 * static_cast<int64_t>(task)] = wall_clock64();
+#endif
     SFA_STRIP_DISPATCH(strip_pipe_task, rd.qlen, a, rd, li, job, sidx, lane, xc)
+#ifdef SFA_TASK_TIMES
+    if (a.task_times && lane == 0) {
+        a.task_times[3 * static_cast<int64_t>(task) + 1] = wall_clock64();
+        a.task_times[3 * static_cast<int64_t>(task) + 2] = simd_position() | (static_cast<unsigned long long>(sidx) << 32);
+    }
+#endif
 }
 
 // Pass 2, CHAINED (one wave per long read, its winning job): the strips are traced from the LAST one upwards, each over its own

@@ -257,6 +257,8 @@ struct sfa_ctx {
     DevBuf d_started;     // counter of the fill's tasks that have begun (IssuePriority)
     DevBuf d_times;       // -DSFA_TASK_TIMES builds: start / end / SIMD position of every wave-task of the last fill
     int64_t n_times = 0;
+    DevBuf d_ltimes;      // ... and of the last pipelined pass 1 over row strips (tools/strip_task_times.py)
+    int64_t n_ltimes = 0;
     sfa::BatchPlan plan;  // plan of the batch being submitted (scratch included)
     sfa_profile_t prof{};
     bool prof_pending = false;
@@ -518,6 +520,11 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
             sa.ticket = c->d_lticket.as<unsigned>();
             const int64_t waves = static_cast<int64_t>(soff[gn]) * n_jobs;
             const dim3 gridp(static_cast<unsigned>((waves + 3) / 4));
+#ifdef SFA_TASK_TIMES
+            if ((rc = c->d_ltimes.reserve(24 * static_cast<size_t>(waves)))) return rc;
+            sa.task_times = c->d_ltimes.as<unsigned long long>();
+            c->n_ltimes = waves;
+#endif
             if (std_dtw)
                 hipLaunchKernelGGL((sfa::sdtw_strip_pipe_kernel<true>), gridp, block, 0, st, sa);
             else
@@ -1873,6 +1880,13 @@ int64_t sfa_debug_task_times(sfa_ctx_t *c, unsigned long long *out, int64_t cap_
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
     const int64_t n = std::min<int64_t>(cap_tasks, c->n_times);
     if (n > 0 && hipMemcpy(out, c->d_times.p, 24 * static_cast<size_t>(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+int64_t sfa_debug_task_times_long(sfa_ctx_t *c, unsigned long long *out, int64_t cap_tasks) {
+    if (!c || !out) return -1;
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    const int64_t n = std::min<int64_t>(cap_tasks, c->n_ltimes);
+    if (n > 0 && hipMemcpy(out, c->d_ltimes.p, 24 * static_cast<size_t>(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return n;
 }
 #endif

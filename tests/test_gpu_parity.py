@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import sigfish_amd as S
-from sigfish_amd import synth
+from sigfish_amd import api, synth
 from tests.util import case_names, load_case, paf_lines_from_results
 
 pytestmark = pytest.mark.gpu
@@ -598,3 +598,51 @@ def test_pass_2_head_start_follows_the_previous_batch(oracle):
         al.set_option("adaptive_margin", 0)
         al.align_db(q, q_off)
         assert al.profile()["trace_margin"] == 500 + 16
+
+
+def test_reference_of_32_megabases_against_its_cut_outs():
+    """Maximum sizes, reference: a 32 Mb contig (3.2 x 10^7 columns per strand, 12 GB of checkpoint offsets beyond 32 bits, column
+    segments for the small batch).  No CPU implementation fills a 250 x 3.2 x 10^7 matrix per read and strand in test time, so a
+    size-independent property: the best alignment of a read against the whole contig is, bit for bit, its best alignment against
+    a 500 000-column cut-out around it (cut at a multiple of the query length, so that the windows of src/sigfish.c:891-901
+    coincide), positions shifted by the cut.  (Reads are NOT expected at their origin here: the reference z-normalises a contig
+    with fp32 accumulators, src/genref.c:23-47, whose sum stops growing near 2 x 10^9 -- beyond ~1.6 x 10^7 k-mers of level ~90
+    the mean is wrong for the reference and for this build alike; tests/campaigns/big_reference.py prints it for 4 .. 128 Mb.)"""
+    lv = synth.kmer_levels(6, 1)
+    ref = api.RefModel.from_records([("big", synth.random_sequence(32_000_000, 11))], lv, 6, 0, 250)
+    rl = int(ref.ref_lengths[0])
+    n, W = 64, 250 * 2000
+    q, q_off, _ = synth.make_reads(ref, n, qlen=250, seed=5, short_frac=0.0)
+    with S.Aligner(ref, 0) as al:
+        a = al.align_db(q, q_off)
+        assert al.align_db(q, q_off).tobytes() == a.tobytes()
+    assert (a["valid"] == 1).all()
+    for i in range(0, n, 8):
+        fwd = a["strand"][i] == ord("+")
+        own = int(a["pos_st"][i]) if fwd else rl - int(a["pos_end"][i])  # column of the hit in its strand's own array
+        lo = max(0, (own - W // 2) // 250 * 250)
+        hi = min(rl, lo + W)
+        f, r = ref.forward[0], ref.reverse[0]
+        sub_f, sub_r = (f[lo:hi], r[rl - hi:rl - lo]) if fwd else (f[rl - hi:rl - lo], r[lo:hi])
+        sub = api.RefModel(["sub"], [hi - lo + 5], [hi - lo], [0], [np.ascontiguousarray(sub_f)], [np.ascontiguousarray(sub_r)])
+        with S.Aligner(sub, 0) as al2:
+            c = al2.align_db(q[q_off[i]:q_off[i + 1]], np.array([0, 250], np.int64))
+        shift = lo if fwd else rl - hi  # positions are reported on the forward strand
+        assert c["score"][0].tobytes() == a["score"][i].tobytes() and c["strand"][0] == a["strand"][i], (i, a[i], c[0])
+        assert int(c["pos_st"][0]) + shift == int(a["pos_st"][i]) and int(c["pos_end"][0]) + shift == int(a["pos_end"][i]), (i, a[i], c[0], lo)
+
+
+def test_batch_of_a_million_reads():
+    """Maximum sizes, batch: 1 000 000 reads in one call (ten times the headline batch; 1 GB of queries), built from 50 000
+    reads repeated twenty times: every repetition must give the rows of the first, which are the rows of the 50 000 alone."""
+    ref, flag, q, q_off, meta = synth.workload("ncov_r9_dna_q250", n_reads=50_000, seed=17)
+    reps = 20
+    lens = q_off[1:] - q_off[:-1]
+    qq = np.tile(q, reps)
+    qo = np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.int64)
+    with S.Aligner(ref, flag) as al:
+        unit = al.align_db(q, q_off)
+        big = al.align_db(qq, qo)
+    assert len(big) == reps * len(unit)
+    for k in range(reps):
+        assert big[k * len(unit):(k + 1) * len(unit)].tobytes() == unit.tobytes(), k
