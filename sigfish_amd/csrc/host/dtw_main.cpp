@@ -406,6 +406,7 @@ static int dtw_run(int argc, char **argv) {
     // (one per context) and the output of batch i-2 run on helper threads, the main thread loads and pre-processes
     // batch i+1.  Batches are printed strictly in order, so the output is the same as the serial loop's. ----
     double t_load = 0, t_proc = 0, t_dtw = 0, t_out = 0;
+    double t_wait_gpu = 0, t_wait_out = 0, t_pin = 0;  // main thread: waiting for a context / for the printer; page-locked staging (re)allocation
     // --profile-cpu=yes (src/dtw_main.c:213-214, src/sigfish.c:1021-1040): the stages of a batch run one after the other,
     // each under its own timer, and the batches are not overlapped.  Host stages are wall time of their fan-out over -t
     // threads, as in the reference; stages that run on the device are the device's own time (HIP events, sfa_get_profile).
@@ -727,9 +728,11 @@ static int dtw_run(int argc, char **argv) {
             }
             const size_t need = static_cast<size_t>(sl.raw_off[n]) + 1;
             if (need > sl.raw_cap) {
+                const double pa = realtime();
                 sfa_pinned_free(sl.raw);
                 sl.raw_cap = need + need / 4;
                 sl.raw = static_cast<int16_t *>(sfa_pinned_alloc(sl.raw_cap * sizeof(int16_t)));
+                t_pin += realtime() - pa;
                 if (!sl.raw) die(std::string("cannot allocate the sample staging buffer: ") + sfa_last_error());
             }
             pool.run(n, [&](int64_t i) {
@@ -747,8 +750,12 @@ static int dtw_run(int argc, char **argv) {
             too_short += (r.status & 1) != 0;
         }
         t_proc += realtime() - a;
+        a = realtime();
         if (gpu_pending[bi % n_ctx].valid()) gpu_pending[bi % n_ctx].get();  // batch bi-n_ctx has its rows, its context is free
+        t_wait_gpu += realtime() - a;
+        a = realtime();
         if (out_pending.valid()) out_pending.get();  // batch bi-n_ctx-1 is printed (its slot is filled next)
+        t_wait_out += realtime() - a;
         if (bi >= n_ctx) {
             Slot *done = &slots[(bi - n_ctx) % n_slots];
             out_pending = std::async(std::launch::async, [&output, done] { output(*done); });
@@ -790,6 +797,9 @@ static int dtw_run(int argc, char **argv) {
         fprintf(stderr, "[dtw_main] Data processing time: %.3f sec (host stages) + %.3f sec (DTW stage, overlapped with the next batch)\n",
                 t_proc, t_dtw);
         fprintf(stderr, "[dtw_main] Data output time: %.3f sec\n", t_out);
+        if (o.verbosity >= 4)
+            fprintf(stderr, "[dtw_main] main thread waited %.3f sec for a free device context and %.3f sec for the printer; page-locked staging (re)allocated in %.3f sec (inside the host stages)\n",
+                    t_wait_gpu, t_wait_out, t_pin);
     }
     if (o.verbosity >= 4) fprintf(stderr, "[dtw_main::%.3f] all output written; releasing the device\n", realtime() - t0);
     g_verbosity = o.verbosity;

@@ -1,5 +1,5 @@
 D=/dev/shm/sfa_tail; mkdir -p $D
-python tools/make_blow5.py tests/golden/data/sp1_dna.blow5 $D/c.blow5 --copies 80000 --compress --jobs 16 | tail -1
+python tools/make_blow5.py tests/golden/data/sp1_dna.blow5 $D/c.blow5 --copies ${COPIES:-80000} --compress --jobs 16 | tail -1
 python - <<'PY'
 import itertools, numpy as np
 lv = np.fromfile("tests/golden/models/syn6.f32", np.float32)
@@ -14,6 +14,6 @@ T0=$(date +%s.%N)
 sigfish_amd/bin/sigfish-amd dtw --kmer-model $D/syn6.model -t 16 -B 2G -K 4096 --verbose 4 tests/golden/data/nCoV-2019.reference.fasta $D/c.blow5 > $D/out.paf 2> $D/err.txt
 T1=$(date +%s.%N)
 python -c "print('wall %.3f' % ($T1-$T0))"
-grep "initialised\|all output\|released\|Data" $D/err.txt
+grep "initialised\|all output\|released\|Data\|waited" $D/err.txt
 done
 rm -rf $D
