@@ -120,7 +120,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
             room = st.f_bavail * st.f_frsize
         except OSError:
             room = 0
-        if long_file and room > 3 * long_copies * 5 * 4200:
+        if long_file and where.startswith("/dev/shm") and room > 3 * long_copies * 5 * 4200:  # (memory-backed scratch only: 6.6 GB at the default size)
             path = os.path.join(d, "compressed_long.blow5")
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
                             "--copies", str(long_copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True)
