@@ -211,3 +211,41 @@ def test_plan_batch_ragged_lengths_share_waves():
     for qd in np.unique(quads)[:200]:
         ls = lens[order][quads == qd]
         assert (np.diff(ls) <= 0).all()
+
+
+def test_plan_batch_invariants_on_random_batches():
+    """Property test of the planner (hypothesis): whatever the lengths, every non-empty read gets exactly one slot, empty reads
+    none, the reads of a wave belong to one class and agree modulo its rows per lane (MixedQuad's condition), the longest comes
+    first, and the task count is quads x chunks."""
+    from hypothesis import given, settings, strategies as st
+    from sigfish_amd.api import plan_batch
+
+    rows_per_lane = lambda l: 4 if l <= 64 else 8 if l <= 128 else 16 if l <= 256 else 32
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.one_of(st.integers(0, 300), st.integers(0, 2048), st.sampled_from([0, 1, 4, 64, 65, 250, 256, 257, 1024, 2048])),
+                    min_size=0, max_size=400),
+           st.lists(st.integers(1, 5000), min_size=1, max_size=12))
+    def check(lens, ref_lens):
+        lens = np.asarray(lens, np.int64)
+        q_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        info, slot = plan_batch(q_off, ref_lens, lane_widening=1)
+        assert (slot[lens == 0] == -1).all()
+        used = slot[lens > 0]
+        assert (used >= 0).all() and len(np.unique(used)) == len(used)
+        if len(used) == 0:
+            assert info["n_quads"] == 0
+            return
+        order = np.argsort(used)
+        quads = used[order] >> 2
+        ls_sorted = lens[lens > 0][order]
+        assert info["n_quads"] == len(np.unique(quads))
+        assert info["n_tasks"] == info["n_quads"] * info["n_chunks"]
+        for qd in np.unique(quads):
+            ls = ls_sorted[quads == qd]
+            R = rows_per_lane(int(ls.max()))
+            assert {rows_per_lane(int(l)) for l in ls} == {R}
+            assert len({int(l) % R for l in ls}) == 1
+            assert (np.diff(ls) <= 0).all()
+
+    check()
