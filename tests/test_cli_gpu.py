@@ -152,3 +152,20 @@ def test_cli_profile_cpu_prints_the_reference_stage_timers(models, extra):
     # without the switch the four lines are not printed
     r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], *extra, c["fasta"], c["blow5"]], capture_output=True, timeout=300)
     assert r.returncode == 0 and "- Parse time" not in r.stderr.decode() and r.stdout.decode() == c["out_text"]
+
+
+def test_cli_verbose_4_reports_where_the_main_thread_waited(models):
+    """--verbose 4: the timeline of a run on stderr -- initialisation, per batch lines, and (round 3) how long the main thread
+    waited for a free device context and for the printer, which is how a run tells whether the host threads or the device set its
+    pace; stdout is the same PAF."""
+    import re
+    c = load_case("dna_default")
+    r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "4", "-K", "2", c["fasta"], c["blow5"]], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+    err = r.stderr.decode()
+    assert re.search(r"\[dtw_main::[0-9.]+\] initialised: input [0-9.]+ s, model \+ reference events [0-9.]+ s, 2 device context\(s\) [0-9.]+ s", err), err
+    m = re.search(r"main thread waited ([0-9.]+) sec for a free device context and ([0-9.]+) sec for the printer; page-locked staging \(re\)allocated in ([0-9.]+) sec", err)
+    assert m, err
+    assert all(float(x) >= 0 for x in m.groups())
+    assert err.count("Entries") >= 6  # three batches of 2 + 2 + 1 reads: a `loaded` and a `processed` line each
