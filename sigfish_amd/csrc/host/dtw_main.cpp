@@ -390,6 +390,19 @@ static int dtw_run(int argc, char **argv) {
         // threshold (waves per SIMD of a single batch) shrinks accordingly
         const int per_dev = n_ctx / static_cast<int>(o.devices.size());
         if (sfa_set_option(ctxs[j], "widen_below", std::max(1, 5 / per_dev)) != SFA_OK) die(sfa_last_error());
+        // SFA_OPTS="name=value,name=value": planner / launch options of the library (sfa_set_option) for experiments from the
+        // command line (tools/e2e_env_ab.sh); rows do not depend on them
+        if (const char *e = getenv("SFA_OPTS")) {
+            std::string all(e);
+            for (size_t p = 0; p < all.size();) {
+                const size_t q = std::min(all.find(',', p), all.size());
+                const std::string kv = all.substr(p, q - p);
+                const size_t eq = kv.find('=');
+                if (eq == std::string::npos || eq == 0) die("SFA_OPTS takes name=value[,name=value...]");
+                if (sfa_set_option(ctxs[j], kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)) != SFA_OK) die(std::string("SFA_OPTS: ") + sfa_last_error());
+                p = q + 1;
+            }
+        }
     }
 
     t_init[2] = realtime() - ti;
