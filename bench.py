@@ -13,13 +13,22 @@ Workload (config.workload = "ncov_r9_dna_q250", BASELINE.json configs[2]): synth
 path (sfa_align_batch_device: plan + fill kernel + finalize + trace kernel + finalize) over one batch of --reads reads
 per GPU whose query events are already resident in HBM; for N > 1 the rows of all timed steps are gathered to rank 0
 over RCCL once, after the last step and inside the timed region.  Reads shard
-across ranks with no data-path collective (weak scaling: every rank gets --reads reads); the reference event model
-is broadcast once, before the timed region.
+across ranks with no data-path collective; the reference event model is broadcast once, before the timed region.
+
+Scaling (the line's `scaling` key; `scaling_definitions` spells both out):
+  weak    (default)          every rank gets --reads reads per step: total work grows with N
+  strong  (--total-reads T)  T reads per step are split over the ranks by contiguous ranges (dist.shard_range), total work is
+                             fixed: BASELINE.json configs[3] is `--workload r10_dna_1mb_q250 --total-reads 1000000 --gpus 8`
+After the timed region, for N > 1, rank 0 checks that the rows it received from every rank are the rows that rank computed
+(`gather_verified`; --no-check-gather skips it).
 
 The JSON line also carries
-  roofline      HBM roofline of the dominant kernel (sdtw_fill_kernel): algorithmic bytes per launch / its mean
-                duration, measured with HIP events on the stream the kernel is launched on; plus the VALU view
-                (cells/s vs lanes*clock/ops_per_cell), which is the bound that actually bites.
+  roofline      of the dominant kernel (sdtw_fill_kernel).  `bound` is "valu": the kernel never materialises the cost matrix,
+                so VALU issue binds, not HBM.  `achieved`/`peak`/`frac` are lane-operations per second: DP
+                cells/s x VALU instructions per cell (counted from the shipped ISA) against 256 CUs x 4 SIMDs x 32 lanes/clk x
+                2.4 GHz.  The HBM view north_star asks for sits beside it as `roofline.hbm` (algorithmic bytes per launch /
+                mean kernel duration, measured with HIP events on the kernel's stream, against 8 TB/s), with the counter
+                traffic and `traffic_over_algorithmic`.
   cpu_baseline  sigfish's own CPU alignment stage (the reference sources compiled into oracle/_ref; kind "reference")
                 timed on this box's host cores on a bounded sample of the same workload; falls back to our CPU
                 restatement (kind "port") when that build is absent.
@@ -116,8 +125,11 @@ def main():
     ap.add_argument("--host-buffers", action="store_true",
                     help="also time sfa_align_batch with HOST query/result buffers (PCIe-inclusive; never `value`)")
     ap.add_argument("--opt", action="append", default=[], help="sfa_set_option key=value (tuning experiments)")
-    ap.add_argument("--check-gather", action="store_true",
-                    help="after the timed region: every rank's rows as rank 0 received them == the rows that rank computed (checksums)")
+    ap.add_argument("--total-reads", type=int, default=None,
+                    help="strong scaling: this many reads per step in total, split over the ranks by contiguous ranges (default: weak, --reads per rank)")
+    ap.add_argument("--check-gather", action="store_true", help="(default for N > 1; kept for old command lines)")
+    ap.add_argument("--no-check-gather", action="store_true",
+                    help="skip the check after the timed region that rank 0 received exactly the rows every rank computed (checksums)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (raw BLOW5 -> PAF through the command line)")
     ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads in the generated BLOW5 files of the end-to-end leg")
     args = ap.parse_args()
@@ -147,8 +159,14 @@ def main():
         dist.init_process_group("gloo")
         t = torch.ones(1, dtype=torch.int64)
         dist.all_reduce(t)
+        line = {"launch_test": True, "n_gpus": int(t.item()), "world": dist.get_world_size()}
+        if args.total_reads is not None:  # strong scaling: every rank reports the range it would align
+            mine = torch.tensor(D.shard_range(args.total_reads, rank, world), dtype=torch.int64)
+            got = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)
+            line.update(scaling="strong", read_ranges=[[int(a), int(b)] for a, b in got])
         if rank == 0:
-            print(json.dumps({"launch_test": True, "n_gpus": int(t.item()), "world": dist.get_world_size()}), flush=True)
+            print(json.dumps(line), flush=True)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -180,7 +198,15 @@ def main():
 
     # ---- this rank's shard of reads: synthetic, generated here, uploaded to HBM before the timed region ----
     qlen = int(re.search(r"_q(\d+)$", args.workload).group(1))  # every workload name ends in its -q value
-    if args.reads is None:
+    if args.total_reads is not None and args.reads is not None:
+        raise SystemExit("--reads (per rank, weak scaling) and --total-reads (all ranks together, strong scaling) exclude each other")
+    if args.total_reads is not None and args.total_reads < world:
+        raise SystemExit(f"--total-reads {args.total_reads} leaves ranks without reads at {world} ranks")
+    strong = args.total_reads is not None
+    if strong:  # this rank's contiguous range of the job's reads
+        lo, hi = D.shard_range(args.total_reads, rank, world)
+        args.reads = hi - lo
+    elif args.reads is None:
         args.reads = 100_000 * 250 // qlen
     q, q_off, _ = synth.make_reads(ref, args.reads, qlen=qlen, seed=1000 + rank)
     n = args.reads
@@ -194,7 +220,8 @@ def main():
     row_bytes = n * S.RESULT_DTYPE.itemsize
     n_slots = max(args.steps, 1)
     d_out = torch.zeros(n_slots * row_bytes, dtype=torch.uint8, device=dev)
-    counts = [n * n_slots] * world
+    shard_reads = [n] * world if not strong else [D.shard_range(args.total_reads, r, world)[1] - D.shard_range(args.total_reads, r, world)[0] for r in range(world)]
+    counts = [c * n_slots for c in shard_reads]
     torch.cuda.synchronize()
 
     fill_ms, trace_ms, launches = [], [], 0
@@ -231,7 +258,8 @@ def main():
         elapsed = float(t.item())
 
     gather_verified = None
-    if args.check_gather:  # outside the timed region: rank r's slice on rank 0 against what rank r holds
+    # outside the timed region: rank r's slice on rank 0 against what rank r holds, and (strong scaling) the work every rank did
+    if (world > 1 or force_dist or args.check_gather) and not args.no_check_gather:
         import zlib
         mine = torch.tensor([zlib.crc32(d_out.cpu().numpy().tobytes())], dtype=torch.int64, device=dev)
         sums = [mine]
@@ -240,15 +268,21 @@ def main():
             dist.all_gather(sums, mine)
         if rank == 0:
             got = gathered.view(np.uint8) if gathered is not None else d_out.cpu().numpy()
-            w = n * n_slots * S.RESULT_DTYPE.itemsize
-            gather_verified = [zlib.crc32(got[r * w:(r + 1) * w].tobytes()) for r in range(world)] == [int(t.item()) for t in sums]
+            item = S.RESULT_DTYPE.itemsize
+            cuts = np.concatenate([[0], np.cumsum(counts)]) * item
+            gather_verified = [zlib.crc32(got[cuts[r]:cuts[r + 1]].tobytes()) for r in range(world)] == [int(t.item()) for t in sums]
+    # cells and algorithmic bytes of the WHOLE job (ranks differ by a read under strong scaling, and by their reads' lengths)
+    job = torch.tensor([cells, alg_bytes, n], dtype=torch.int64, device=dev)
+    if world > 1 or force_dist:
+        dist.all_reduce(job)
+    job_cells, job_bytes, job_reads = (int(v) for v in job.tolist())
 
     if rank != 0:
         al.close()
         dist.destroy_process_group()
         return
 
-    total_reads = n * world * args.steps
+    total_reads = job_reads * args.steps
     value = total_reads / elapsed
     kern_s = (sum(fill_ms) / max(len(fill_ms), 1)) / 1e3  # mean fill time per step (all fill launches of a step)
     launches_per_step = max(launches // max(args.steps, 1), 1)
@@ -280,28 +314,36 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
+        "scaling_definitions": {"weak": "every rank aligns --reads reads per step: total work grows with n_gpus (default)",
+                                "strong": "--total-reads reads per step are split over the ranks by contiguous ranges: total work is fixed"},
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "library_build": S.build_id(),
         **({"gather_verified": gather_verified} if gather_verified is not None else {}),
-        "config": {"workload": args.workload, "reads_per_gpu": n, "query_events": qlen, "ref_kmers": int(ref.ref_lengths.sum()),
+        "config": {"workload": args.workload, "reads_per_gpu": n, **({"total_reads": args.total_reads} if strong else {}),
+                   "reads_per_rank": shard_reads, "query_events": qlen, "ref_kmers": int(ref.ref_lengths.sum()),
                    "strands": strands, "sharding": f"reads x{world}", "cells_per_read_full": qlen * cols},
-        "dp_cells_per_s": round(cells * world * args.steps / elapsed, 1),
+        "dp_cells_per_s": round(job_cells * args.steps / elapsed, 1),
+        # per launch of the dominant kernel ON RANK 0 (n reads): the kernel is VALU-issue bound, the HBM view sits beside it
         "roofline": {
-            "bound": "hbm", "kernel": "sdtw_fill_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
+            "bound": "valu", "kernel": "sdtw_fill_kernel",
+            "achieved": round(cells_per_s_kernel * ops_per_cell / 1e12, 4), "peak": round(VALU_LANE_OPS / 1e12, 4), "unit": "Tlane-op/s",
+            "frac": round(cells_per_s_kernel * ops_per_cell / VALU_LANE_OPS, 4),
+            "what": "DP cells/s of the kernel x VALU instructions per cell (shipped ISA) against 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz; "
+                    "`attainable_frac` is the measured issue rate against what this opcode mix reaches in isolation (v_min3 is half rate)",
+            "cells_per_s": round(cells_per_s_kernel, 1), "ops_per_cell": round(ops_per_cell, 4), "ops_per_cell_source": ops_src,
+            "peak_cells_per_s": round(VALU_LANE_OPS / ops_per_cell, 1),
+            **(issue or {"attainable_frac": None}),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_over_algorithmic": None if traffic is None else round(traffic * launches_per_step / alg_bytes, 4),
             "algorithmic_bytes_per_step": alg_bytes, "fill_launches_per_step": launches_per_step,
             "kernel_ms_per_step": round(kern_s * 1e3, 3),
             "trace_kernel_ms_per_step": round(sum(trace_ms) / max(len(trace_ms), 1), 3),
-            # `frac` is against full-rate issue at the nominal clock, which this opcode mix cannot reach (v_min3 is half rate,
-            # the chip sustains ~2.1-2.2 GHz under this load); `attainable_frac` (when this build was profiled) is the measured
-            # issue rate against what the mix reaches in isolation -- the two must not be confused
-            "valu": {"cells_per_s": round(cells_per_s_kernel, 1), "ops_per_cell": round(ops_per_cell, 4), "ops_per_cell_source": ops_src,
-                     "peak_cells_per_s": round(VALU_LANE_OPS / ops_per_cell, 1),
-                     "frac": round(cells_per_s_kernel * ops_per_cell / VALU_LANE_OPS, 4),
-                     **(issue or {"attainable_frac": None})},
+            "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
+                    "what": "algorithmic bytes per launch (SURVEY.md 8d: 4 B per query event + 4 B per reference level and strand + 32 B per read) "
+                            "/ mean kernel duration"},
         },
     }
 

@@ -338,7 +338,9 @@ int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_i
 int32_t sfa_r2qevent_map(const sfa_result_t *r, const sfa_event_t *events, int64_t qstart, int64_t qend, const float *ref_array,
                          int32_t ref_len, int32_t ref_st_offset, uint32_t flag, int32_t *pairs, int32_t cap_pairs);
 
-/* read_model (src/model.c:38-131): text k-mer model -> level_mean[4^k] (levels must hold 262144 floats). */
+/* read_model (src/model.c:38-131): text k-mer model -> level_mean[4^k] (levels must hold 262144 floats).  Accepts and refuses what
+ * the reference does; rows it would only have logged as corrupted (src/model.c:98-100) are counted like it counts them and listed
+ * in sfa_last_error() after a successful return (empty string: none). */
 int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k);
 
 /* Sequential BLOW5 reader (zlib / svb-zd / uncompressed), the subset of slow5lib the path uses. */
@@ -349,6 +351,14 @@ const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key); /* header attribute
  * meta = {digitisation, offset, range, sampling_rate}. */
 int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const int16_t **raw, int64_t *n_raw);
 void sfa_blow5_close(sfa_blow5_t *f);
+/* One rank's part of a read-sharded run (replaces the whole-file loop of src/dtw_main.c:299-326 by G loops over disjoint parts;
+ * records are framed by their u64 size prefixes only, slow5lib/src/slow5.c:3218-3266, so a part is found by walking them).
+ * Call after sfa_blow5_open and before the first sfa_blow5_next; past the selection sfa_blow5_next returns 0.
+ *   sfa_blow5_select_shard    the records whose size prefix starts in the r-th of G equal byte slices of the record region:
+ *                             the G shards are every record exactly once, in file order (regular files only)
+ *   sfa_blow5_select_records  records [first, first + count) by position in the file (count < 0: to the end) */
+int sfa_blow5_select_shard(sfa_blow5_t *f, int32_t r, int32_t G);
+int sfa_blow5_select_records(sfa_blow5_t *f, int64_t first, int64_t count);
 
 /* Free and total memory of a device in bytes (hipMemGetInfo), for callers sizing their batches. */
 int sfa_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);

@@ -54,7 +54,7 @@ class SfaEvent(C.Structure):
 SYMBOLS = ["sfa_init", "sfa_init_devices", "sfa_n_devices", "sfa_align_batch", "sfa_submit_batch", "sfa_wait_batch", "sfa_align_batch_device", "sfa_align_events", "sfa_align_raw", "sfa_align_raw_ex", "sfa_align_blow5", "sfa_inflate_zlib_device", "sfa_pinned_alloc", "sfa_pinned_free", "sfa_sync",
            "sfa_get_profile", "sfa_stream", "sfa_set_option", "sfa_plan_batch", "sfa_destroy", "sfa_last_error", "sfa_version", "sfa_build_id", "sfa_gen_ref_record",
            "sfa_znormalise", "sfa_paf_row", "sfa_sam_row", "sfa_r2qevent_map", "sfa_detect_events", "sfa_select_query", "sfa_read_kmer_model",
-           "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close", "sfa_inflate_zlib", "sfa_inflate_zlib_pair", "sfa_device_memory"]
+           "sfa_blow5_open", "sfa_blow5_attr", "sfa_blow5_next", "sfa_blow5_close", "sfa_blow5_select_shard", "sfa_blow5_select_records", "sfa_inflate_zlib", "sfa_inflate_zlib_pair", "sfa_device_memory"]
 
 _lib = None
 
@@ -122,6 +122,8 @@ def load():
     L.sfa_blow5_next.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i16p), i64p]
     L.sfa_blow5_close.argtypes = [vp]
     L.sfa_blow5_close.restype = None
+    L.sfa_blow5_select_shard.argtypes = [vp, C.c_int32, C.c_int32]
+    L.sfa_blow5_select_records.argtypes = [vp, C.c_int64, C.c_int64]
     L.sfa_inflate_zlib.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_size_t]
     L.sfa_inflate_zlib_pair.restype = C.c_int
     L.sfa_inflate_zlib_pair.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, i64p]

@@ -336,6 +336,18 @@ class Blow5File:
         v = self._L.sfa_blow5_attr(self._h, key.encode())
         return None if v is None else v.decode()
 
+    def select_shard(self, r, G):
+        """Only the records starting in the r-th of G equal byte slices of the file (one rank of a read-sharded run)."""
+        if self._L.sfa_blow5_select_shard(self._h, r, G) != 0:
+            raise SfaError(self._L.sfa_last_error().decode())
+        return self
+
+    def select_records(self, first, count=-1):
+        """Only records [first, first + count) by position in the file (count < 0: to the end)."""
+        if self._L.sfa_blow5_select_records(self._h, first, count) != 0:
+            raise SfaError(self._L.sfa_last_error().decode())
+        return self
+
     def __iter__(self):
         rid = C.c_char_p()
         meta = (C.c_double * 4)()
@@ -390,11 +402,14 @@ def select_query(events, raw, meta, prefix_size=50, query_size=250, flag=0, pore
     return bool(keep), qs.value, qe.value
 
 
-def read_kmer_model(path):
+def read_kmer_model(path, warnings=None):
+    """read_model: (level_mean[4^k], k).  Rows the reference would only log as corrupted are appended to `warnings` (a list)."""
     lv = np.zeros(262144, np.float32)
     k = C.c_uint32()
-    _check(_lib.load().sfa_read_kmer_model(str(path).encode(), lv.ctypes.data_as(_lib.f32p), C.byref(k)),
-           "sfa_read_kmer_model")
+    L = _lib.load()
+    _check(L.sfa_read_kmer_model(str(path).encode(), lv.ctypes.data_as(_lib.f32p), C.byref(k)), "sfa_read_kmer_model")
+    if warnings is not None:
+        warnings.extend(w for w in L.sfa_last_error().decode().split("\n") if w)
     return lv[:4 ** k.value].copy(), k.value
 
 

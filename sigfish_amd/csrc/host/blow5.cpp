@@ -10,6 +10,7 @@
 #include <immintrin.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstring>
 
 namespace sfa {
@@ -166,7 +167,8 @@ void Blow5Reader::start_prefault(size_t window) {
     if (!map_) return;
     consumed_ = map_pos_;
     const uint8_t *base = map_;
-    const size_t size = map_size_, start = map_pos_;
+    // (a shard's helper stops a page past the shard: the next rank's pages are the next rank's business)
+    const size_t size = limit_pos_ < map_size_ ? std::min<size_t>(map_size_, static_cast<size_t>(limit_pos_) + 4096) : map_size_, start = map_pos_;
     prefault_ = std::thread([this, base, size, start, window] {
         unsigned sink = 0;
         for (size_t pos = start & ~size_t(4095); pos < size && !prefault_quit_; pos += 4096) {
@@ -226,6 +228,8 @@ bool Blow5Reader::open(const std::string &path) {
         err_ = path + ": truncated BLOW5 header";
         return false;
     }
+    data_begin_ = pos_ = 68 + static_cast<uint64_t>(hsize);
+    limit_pos_ = limit_records_ = UINT64_MAX;
     if (record_press_ > 1) {
         err_ = path + ": record compression method " + std::to_string(record_press_) + " is not supported (zlib or none only)";
         return false;
@@ -262,8 +266,62 @@ bool Blow5Reader::open(const std::string &path) {
     return true;
 }
 
+int Blow5Reader::skip_one() {
+    if (map_) {
+        const uint8_t *m;
+        size_t n;
+        return next_view(&m, &n);
+    }
+    if (!fp_) return -1;
+    uint64_t size = 0;
+    const size_t got = fread(&size, 1, sizeof size, fp_);
+    if (got != sizeof size) {
+        if (got == sizeof kEof && memcmp(&size, kEof, sizeof kEof) == 0) return 0;
+        err_ = "malformed BLOW5: missing end-of-file marker";
+        return -1;
+    }
+    if (size > file_size_ || fseeko(fp_, static_cast<off_t>(size), SEEK_CUR) != 0) {
+        err_ = "malformed BLOW5: truncated record";
+        return -1;
+    }
+    pos_ += 8 + size;
+    return 1;
+}
+
+bool Blow5Reader::select_records(uint64_t first, uint64_t count) {
+    for (uint64_t i = 0; i < first; ++i) {
+        const int rc = skip_one();
+        if (rc < 0) return false;
+        if (rc == 0) break;  // a range beyond the end of the file is empty, not an error
+    }
+    limit_records_ = count;
+    return true;
+}
+
+bool Blow5Reader::select_shard(uint32_t r, uint32_t G) {
+    if (G == 0 || r >= G) {
+        err_ = "shard index out of range";
+        return false;
+    }
+    if (file_size_ == UINT64_MAX || file_size_ < data_begin_ + sizeof kEof) {
+        err_ = "sharding by byte ranges needs a regular, complete BLOW5 file";
+        return false;
+    }
+    const uint64_t region = file_size_ - sizeof kEof - data_begin_;
+    const auto cut = [&](uint32_t k) { return data_begin_ + static_cast<uint64_t>(static_cast<unsigned __int128>(region) * k / G); };
+    const uint64_t lo = cut(r);
+    while (pos_ < lo) {
+        const int rc = skip_one();
+        if (rc < 0) return false;
+        if (rc == 0) break;
+    }
+    limit_pos_ = r + 1 == G ? UINT64_MAX : cut(r + 1);  // the last shard runs into the end-of-file marker like an unsharded read
+    return true;
+}
+
 int Blow5Reader::next_view(const uint8_t **mem, size_t *size) {
     if (!map_) return -2;  // caller falls back to next_mem()
+    if (limit_records_ == 0 || pos_ >= limit_pos_) return 0;
     if (map_pos_ + sizeof kEof <= map_size_ && map_size_ - map_pos_ == sizeof kEof && memcmp(map_ + map_pos_, kEof, sizeof kEof) == 0) return 0;
     if (map_pos_ + 8 > map_size_) {
         err_ = "malformed BLOW5: missing end-of-file marker";
@@ -278,12 +336,15 @@ int Blow5Reader::next_view(const uint8_t **mem, size_t *size) {
     *mem = map_ + map_pos_ + 8;
     *size = static_cast<size_t>(sz);
     map_pos_ += 8 + static_cast<size_t>(sz);
+    pos_ = map_pos_;
+    if (limit_records_ != UINT64_MAX) --limit_records_;
     consumed_.store(map_pos_, std::memory_order_relaxed);
     return 1;
 }
 
 int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
     if (!fp_) return -1;
+    if (limit_records_ == 0 || pos_ >= limit_pos_) return 0;
     uint64_t size = 0;
     const size_t got = fread(&size, 1, sizeof size, fp_);
     if (got != sizeof size) {
@@ -300,6 +361,8 @@ int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
         err_ = "malformed BLOW5: truncated record";
         return -1;
     }
+    pos_ += 8 + size;
+    if (limit_records_ != UINT64_MAX) --limit_records_;
     return 1;
 }
 
@@ -413,6 +476,13 @@ void Blow5Reader::inflate_pair(const uint8_t *const mem[2], const size_t size[2]
 }
 
 int Blow5Reader::next(Blow5Record *rec) {
+    if (map_) {  // one position per reader: the iterator that a selection walked is the one that reads on
+        const uint8_t *mem;
+        size_t size;
+        const int rc = next_view(&mem, &size);
+        if (rc <= 0) return rc;
+        return parse(mem, size, rec, &err_) ? 1 : -1;
+    }
     const int rc = next_mem(&buf_);
     if (rc <= 0) return rc;
     return parse(buf_, rec, &err_) ? 1 : -1;

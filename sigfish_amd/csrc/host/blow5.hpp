@@ -66,9 +66,23 @@ class Blow5Reader {
     // touch of a mapped page is a fault (0.25-0.4 us; a 4 KB record is a page), and next_view() runs on the caller's one
     // thread -- 0.16 s of "loading" per 400 000 records that nothing overlapped.  The helper takes the faults instead.
     void start_prefault(size_t window = size_t(256) << 20);
+    // One rank's part of a read-sharded run.  Records are framed by their u64 size prefixes and nothing else
+    // (slow5lib/src/slow5.c:3218-3266), so skipping means walking the prefixes: one touch per record, no decompression.
+    //   select_records(first, count)  records [first, first + count) by position in the file (count = UINT64_MAX: to the end)
+    //   select_shard(r, G)            the records whose size prefix starts in the r-th of G equal byte slices of the record
+    //                                 region: needs no record count beforehand, balances the ranks by bytes, and the G shards
+    //                                 together are every record exactly once, in file order (regular files only)
+    // Call after open(), before the first next*().  Past the selection next*() return 0, as at the end of the file.
+    bool select_records(uint64_t first, uint64_t count);
+    bool select_shard(uint32_t r, uint32_t G);
 
   private:
     void stop_prefault();
+    int skip_one();                        // 1: a record skipped, 0: end of file, -1: error
+    uint64_t data_begin_ = 0;              // offset of the first record's size prefix
+    uint64_t pos_ = 0;                     // offset of the next record's size prefix (both iterators keep it)
+    uint64_t limit_pos_ = UINT64_MAX;      // selection: records starting at or beyond this offset are not ours
+    uint64_t limit_records_ = UINT64_MAX;  // selection: records still to hand out
     std::thread prefault_;
     std::atomic<bool> prefault_quit_{false};
     std::atomic<size_t> consumed_{0};  // copy of map_pos_ for the helper

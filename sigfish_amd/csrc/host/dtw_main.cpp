@@ -5,10 +5,16 @@
 // Host stages run on a thread fan-out per batch (parse, events, normalise: src/sigfish.c:317-505); the DTW stage
 // is one call into the C-ABI (sfa_align_events, the align_db hook).  There is no CPU DTW path in this binary.
 #include <getopt.h>
+#include <sys/prctl.h>
 #include <sys/resource.h>
 #include <sys/time.h>
+#include <sys/wait.h>
+#include <signal.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <condition_variable>
 #include <functional>
 #include <future>
@@ -46,6 +52,11 @@ struct Opt {
     int host_inflate = 0;      // --host-inflate: compressed records are inflated on host threads and parsed + decoded on the GPU
     int hybrid_every = -1;     // --hybrid-parse N: every Nth batch goes to the device as it is in the file, the others through host threads (0: off, -1: auto)
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
+    // read sharding over processes (one per GPU): what part of the file THIS process maps
+    int ranks = 0;                       // --ranks G: start G processes on disjoint parts of the file, print their output in rank order (0: one per distinct device)
+    int shard_r = 0, shard_n = 1;        // --shard r/G: the records starting in the r-th of G equal byte slices of the file
+    int64_t range_a = 0, range_b = -1;   // --read-range A:B: records [A, B) by position in the file (B omitted: to the end)
+    bool no_header = false;              // --no-header: no SAM header (every rank but the first of a sharded run)
     const char *model_file = nullptr;
     const char *pore = nullptr;
     int pore_flag = 0;  // 0 r9, 1 r10, 2 rna004
@@ -98,7 +109,12 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --host-inflate             inflate the records on host threads, parse and decode them on the GPU [off]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [0]\n   --streams INT              device contexts taking batches in turn [2]\n\nadvanced options:\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --host-inflate             inflate the records on host threads, parse and decode them on the GPU [off]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [0]\n   --streams INT              device contexts taking batches in turn [2]\n");
+    fprintf(fp, "   --ranks INT                read-shard the run over INT processes (rank r: device r of the list, -t/INT threads, the r-th\n"
+                "                              byte slice of the file); output is printed in rank order = file order [one per distinct device]\n"
+                "   --shard r/G                map only the records starting in the r-th of G equal byte slices of the file\n"
+                "   --read-range A:B           map only records A..B-1 of the file (B omitted: to the end)\n"
+                "   --no-header                do not print the SAM header (ranks after the first)\n\nadvanced options:\n");
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -201,6 +217,88 @@ class WorkerPool {
     bool stop_ = false;
 };
 
+// ---- read sharding over processes (the reference's analogue is the serial loop src/dtw_main.c:299-326) ----
+// `--ranks G`: this process becomes a supervisor BEFORE anything has touched the GPU (no HIP call is made ahead of sfa_init,
+// and the supervisor never makes one).  It forks G ranks; rank r continues into the ordinary run with --shard r/G, device r of
+// the --device list and its share of the host threads.  Rank 0 writes to the supervisor's own stdout; the later ranks write
+// into pipes that the supervisor drains into memory as they run (a rank never waits for the printer) and prints in rank order
+// once the ranks in front have finished -- the "gather of PAF rows".  Shards are contiguous in the file and disjoint, every
+// rank prints its reads in file order (src/sigfish.c:1051-1086), so the concatenation is the single-process output byte for byte.
+// Returns -1 in a rank (which carries on with `o` rewritten), the exit status in the supervisor.
+int supervise_ranks(Opt &o, double t0) {
+    const int G = o.ranks;
+    struct Rank {
+        pid_t pid = -1;
+        int fd = -1;  // read end of the rank's stdout pipe (rank 0: none)
+        std::string out;
+        int status = -1;
+        double wall = 0;
+        std::thread th;
+    };
+    std::vector<Rank> rk(G);
+    fflush(stdout);
+    fflush(stderr);
+    const int threads_each = std::max(1, o.threads / G);
+    for (int r = 0; r < G; ++r) {
+        int pfd[2] = {-1, -1};
+        if (r > 0 && pipe(pfd) != 0) die("--ranks: cannot create a pipe");
+        const pid_t pid = fork();
+        if (pid < 0) die("--ranks: cannot start a rank (fork failed)");
+        if (pid == 0) {  // the rank
+            prctl(PR_SET_PDEATHSIG, SIGTERM);  // a supervisor that dies takes its ranks with it
+            for (int q = 1; q < r; ++q) close(rk[q].fd);
+            if (r > 0) {
+                close(pfd[0]);
+                if (dup2(pfd[1], STDOUT_FILENO) < 0) _exit(EXIT_FAILURE);
+                close(pfd[1]);
+            }
+            o.shard_r = r;
+            o.shard_n = G;
+            o.ranks = 1;
+            o.threads = threads_each;
+            o.devices = {o.devices[r % o.devices.size()]};
+            o.no_header = o.no_header || r > 0;
+            return -1;
+        }
+        rk[r].pid = pid;
+        if (r > 0) {
+            close(pfd[1]);
+            rk[r].fd = pfd[0];
+        }
+    }
+    for (int r = 0; r < G; ++r)
+        rk[r].th = std::thread([&rk, r, t0] {
+            Rank &k = rk[r];
+            if (k.fd >= 0) {
+                char buf[1 << 16];
+                for (;;) {
+                    const ssize_t n = read(k.fd, buf, sizeof buf);
+                    if (n > 0) k.out.append(buf, static_cast<size_t>(n));
+                    else if (n == 0 || errno != EINTR) break;
+                }
+                close(k.fd);
+            }
+            int st = 0;
+            while (waitpid(k.pid, &st, 0) < 0 && errno == EINTR) {}
+            k.status = st;
+            k.wall = realtime() - t0;
+        });
+    int rc = EXIT_SUCCESS;
+    for (int r = 0; r < G; ++r) {
+        rk[r].th.join();
+        const bool ok = WIFEXITED(rk[r].status) && WEXITSTATUS(rk[r].status) == 0;
+        if (o.verbosity >= 3)
+            fprintf(stderr, "[dtw_main] rank %d/%d (device %d, %d host threads): %s after %.3f sec, %zu bytes of output gathered\n", r, G,
+                    o.devices[r % o.devices.size()], threads_each, ok ? "done" : "FAILED", rk[r].wall, rk[r].out.size());
+        if (!ok) rc = EXIT_FAILURE;
+        if (rc == EXIT_SUCCESS && !rk[r].out.empty() && fwrite(rk[r].out.data(), 1, rk[r].out.size(), stdout) != rk[r].out.size()) rc = EXIT_FAILURE;
+        std::string().swap(rk[r].out);
+    }
+    fflush(stdout);
+    if (rc != EXIT_SUCCESS) fprintf(stderr, "[sigfish-amd] ERROR: a rank of the sharded run failed; output is incomplete\n");
+    return rc;
+}
+
 }  // namespace
 
 static int dtw_run(int argc, char **argv);
@@ -240,6 +338,8 @@ static int dtw_run(int argc, char **argv) {
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
                           {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   {"hybrid-parse", required_argument, 0, 18},   {"host-inflate", no_argument, 0, 19},
+                          {"ranks", required_argument, 0, 20},      {"shard", required_argument, 0, 21},
+                          {"read-range", required_argument, 0, 22}, {"no-header", no_argument, 0, 23},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -298,6 +398,20 @@ static int dtw_run(int argc, char **argv) {
                 o.hybrid_every = atoi(optarg);
                 if (o.hybrid_every < 0 || o.hybrid_every == 1) die("--hybrid-parse takes 0 (off) or an integer >= 2 (use --gpu-parse for every batch)");
                 break;
+            case 20: o.ranks = atoi(optarg); if (o.ranks < 1 || o.ranks > 64) die("--ranks should be 1..64"); break;
+            case 21:
+                if (sscanf(optarg, "%d/%d", &o.shard_r, &o.shard_n) != 2 || o.shard_n < 1 || o.shard_r < 0 || o.shard_r >= o.shard_n)
+                    die("--shard takes r/G with 0 <= r < G");
+                break;
+            case 22: {
+                char *e = nullptr;
+                o.range_a = strtoll(optarg, &e, 10);
+                if (e == optarg || *e != ':' || o.range_a < 0) die("--read-range takes A:B (records A up to, not including, B; B may be omitted)");
+                o.range_b = e[1] ? strtoll(e + 1, &e, 10) : -1;
+                if (*e || (o.range_b >= 0 && o.range_b < o.range_a)) die("--read-range takes A:B (records A up to, not including, B; B may be omitted)");
+                break;
+            }
+            case 23: o.no_header = true; break;
             case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }
@@ -319,11 +433,28 @@ static int dtw_run(int argc, char **argv) {
         if (o.flag & F_END) die("Mapping from query end is not compatible with auto query start detection.");
     }
 
+    if (o.shard_n > 1 && (o.range_a > 0 || o.range_b >= 0)) die("--shard and --read-range exclude each other");
+    if (o.ranks == 0) {  // one process per DISTINCT device of the list; a device listed twice is two contexts of one process
+        std::vector<int> d = o.devices;
+        std::sort(d.begin(), d.end());
+        o.ranks = static_cast<int>(std::unique(d.begin(), d.end()) - d.begin());
+    }
+    if (o.ranks > 1) {
+        if (o.shard_n > 1 || o.range_a > 0 || o.range_b >= 0) die("--ranks shards the whole file: it cannot be combined with --shard or --read-range");
+        if (o.debug_break >= 0) die("--debug-break counts the batches of one process: use --ranks 1 with it");
+        const int rc = supervise_ranks(o, t0);
+        if (rc >= 0) return rc;
+    }
+
     // ---- init_core(), src/sigfish.c:81-207 ----
     double t_init[4] = {0, 0, 0, 0};  // reader, model + reference events, device contexts, (teardown)
     double ti = realtime();
     sfa::Blow5Reader reader;
     if (!reader.open(blow5)) die(reader.error());
+    if (o.shard_n > 1 && !reader.select_shard(static_cast<uint32_t>(o.shard_r), static_cast<uint32_t>(o.shard_n))) die(reader.error());
+    if ((o.range_a > 0 || o.range_b >= 0) &&
+        !reader.select_records(static_cast<uint64_t>(o.range_a), o.range_b < 0 ? UINT64_MAX : static_cast<uint64_t>(o.range_b - o.range_a)))
+        die(reader.error());
     reader.start_prefault();  // a helper thread takes the page faults of the mapped file ahead of the batch loop (blow5.hpp)
     t_init[0] = realtime() - ti;
     ti = realtime();
@@ -344,7 +475,9 @@ static int dtw_run(int argc, char **argv) {
     std::vector<float> levels;
     uint32_t k = 0;
     std::string err;
-    if (!sfa::read_kmer_model(o.model_file, &levels, &k, &err)) die(err);
+    std::string model_warnings;
+    if (!sfa::read_kmer_model(o.model_file, &levels, &k, &err, &model_warnings)) die(err);
+    if (!model_warnings.empty() && o.verbosity >= 1) fprintf(stderr, "[sigfish-amd] ERROR: %s", model_warnings.c_str());  // logged, not fatal: src/model.c:98-100
     std::vector<sfa::FastaRecord> contigs;
     if (!sfa::read_fasta(fasta, &contigs, &err)) die(err);
     if (contigs.empty()) die(std::string("no sequences in ") + fasta);
@@ -410,7 +543,7 @@ static int dtw_run(int argc, char **argv) {
         fprintf(stderr, "[dtw_main::%.3f] initialised: input %.3f s, model + reference events %.3f s, %d device context(s) %.3f s\n", realtime() - t0,
                 t_init[0], t_init[1], n_ctx, t_init[2]);
 
-    if (o.flag & F_SAM) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
+    if ((o.flag & F_SAM) && !o.no_header) {  // sam_hdr_wr(), src/dtw_main.c:118-123 (LN is the k-mer count, as the reference prints it)
         for (int32_t i = 0; i < nref; ++i) fprintf(stdout, "@SQ\tSN:%s\tLN:%ld\n", contigs[i].name.c_str(), static_cast<long>(ref_len[i]));
         fprintf(stdout, "@PG\tID:sigfish\tPN:sigfish\tVN:0.2.0\n");
     }

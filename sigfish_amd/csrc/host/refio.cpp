@@ -65,7 +65,7 @@ bool read_fasta(const std::string &path, std::vector<FastaRecord> *out, std::str
     return true;
 }
 
-bool read_kmer_model(const std::string &path, std::vector<float> *level_mean, uint32_t *k_out, std::string *err) {
+bool read_kmer_model(const std::string &path, std::vector<float> *level_mean, uint32_t *k_out, std::string *err, std::string *warnings) {
     FILE *fp = fopen(path.c_str(), "r");
     if (!fp) {
         *err = "cannot open k-mer model " + path;
@@ -76,17 +76,25 @@ bool read_kmer_model(const std::string &path, std::vector<float> *level_mean, ui
     level_mean->clear();
     char *line = nullptr;
     size_t cap = 0;
-    ssize_t len;
     int line_no = 0;
     bool ok = true;
-    while ((len = getline(&line, &cap, fp)) != -1) {
+    // the three header spellings the reference knows, newline included (src/model.c:63-65); any other line that begins with
+    // "kmer" is a table row to it -- one that does not parse, is counted, and makes the table one entry too long
+    static const char *const kHeaders[3] = {"kmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\tweight\n", "kmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n",
+                                            "kmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\tig_lambda\tweight\n"};
+    while (getline(&line, &cap, fp) != -1) {
         ++line_no;
-        if (line[0] == '#' || line[0] == '\n' || line[0] == '\r' || strncmp(line, "kmer\t", 5) == 0) {
-            char key[64];
+        if (line[0] == '#' || line[0] == '\n' || line[0] == '\r' || !strcmp(line, kHeaders[0]) || !strcmp(line, kHeaders[1]) || !strcmp(line, kHeaders[2])) {
+            char key[1000];
             int val = 0;
-            if (sscanf(line, "%63s\t%d", key, &val) == 2 && strcmp(key, "#k") == 0) {
-                if (val <= 0 || val > 9) {
-                    *err = "k-mer size (#k " + std::to_string(val) + ") in " + path + " is invalid (1..9)";
+            if (sscanf(line, "%999s\t%d", key, &val) == 2 && strcmp(key, "#k") == 0) {  // src/model.c:69-84; may come more than once, the last one counts
+                if (val <= 0) {
+                    *err = "k-mer size (#k\t" + std::to_string(val) + ") in file " + path + " is invalid.";
+                    ok = false;
+                    break;
+                }
+                if (val > 9) {
+                    *err = "k-mer size (#k\t" + std::to_string(val) + ") in file " + path + " larger than MAX_KMER_SIZE (9).";
                     ok = false;
                     break;
                 }
@@ -95,24 +103,25 @@ bool read_kmer_model(const std::string &path, std::vector<float> *level_mean, ui
             }
             continue;
         }
+        // src/model.c:90-100: a row that does not give three fields is reported and COUNTED, the run goes on.  Its level_mean is
+        // the parsed one when the row got that far; otherwise the reference leaves its table entry as malloc returned it -- 0 here.
         char kmer[64];
-        float mean, stdv;
-        if (sscanf(line, "%63s\t%f\t%f", kmer, &mean, &stdv) != 3) {
-            *err = path + " is corrupted at line " + std::to_string(line_no);
-            ok = false;
-            break;
-        }
-        level_mean->push_back(mean);
-        if (level_mean->size() > want) {
-            *err = path + " has too many entries (expected " + std::to_string(want) + " k-mers)";
+        float mean = 0.f, stdv = 0.f;
+        const int got = sscanf(line, "%63s\t%f\t%f", kmer, &mean, &stdv);
+        if (got != 3 && warnings)
+            *warnings += "File " + path + " is corrupted at line " + std::to_string(line_no) + ". Does the format adhere to examples at test/r9-models?\n";
+        level_mean->push_back(got >= 2 ? mean : 0.f);
+        if (level_mean->size() > want) {  // src/model.c:101-106
+            *err = "File " + path + " has too many entries. Expected " + std::to_string(want) + " kmers in the model, but file had more than that";
             ok = false;
             break;
         }
     }
     free(line);
     fclose(fp);
-    if (ok && level_mean->size() != want) {
-        *err = path + " ended prematurely: expected " + std::to_string(want) + " k-mers, found " + std::to_string(level_mean->size());
+    if (ok && level_mean->size() != want) {  // src/model.c:111-116
+        *err = "File " + path + " prematurely ended. Expected " + std::to_string(want) + " kmers in the model, but file had only " +
+               std::to_string(level_mean->size());
         ok = false;
     }
     *k_out = k;

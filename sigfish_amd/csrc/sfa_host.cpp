@@ -229,12 +229,13 @@ int sfa_sam_row(char *buf, size_t cap, const sfa_result_t *r, const char *read_i
 int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k) {
     if (!path || !levels || !k) return SFA_EINVAL;
     std::vector<float> lv;
-    std::string err;
-    if (!sfa::read_kmer_model(path, &lv, k, &err)) {
+    std::string err, warn;
+    if (!sfa::read_kmer_model(path, &lv, k, &err, &warn)) {
         sfa_set_error_(err.c_str());
         return SFA_EINVAL;
     }
     memcpy(levels, lv.data(), sizeof(float) * lv.size());
+    sfa_set_error_(warn.c_str());  // rows the reference would only have logged (src/model.c:98-100); empty when there were none
     return SFA_OK;
 }
 
@@ -285,6 +286,20 @@ int sfa_blow5_next(sfa_blow5_t *f, const char **read_id, double meta[4], const i
 }
 
 void sfa_blow5_close(sfa_blow5_t *f) { delete f; }
+
+int sfa_blow5_select_shard(sfa_blow5_t *f, int32_t r, int32_t G) {
+    if (!f || G < 1 || r < 0 || r >= G) return SFA_EINVAL;
+    if (f->reader.select_shard(static_cast<uint32_t>(r), static_cast<uint32_t>(G))) return SFA_OK;
+    sfa_set_error_(f->reader.error().c_str());
+    return SFA_EINVAL;
+}
+
+int sfa_blow5_select_records(sfa_blow5_t *f, int64_t first, int64_t count) {
+    if (!f || first < 0) return SFA_EINVAL;
+    if (f->reader.select_records(static_cast<uint64_t>(first), count < 0 ? UINT64_MAX : static_cast<uint64_t>(count))) return SFA_OK;
+    sfa_set_error_(f->reader.error().c_str());
+    return SFA_EINVAL;
+}
 
 int64_t sfa_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap) {
     if (!in || (!out && cap)) return SFA_EINVAL;

@@ -27,7 +27,13 @@ def test_bench_json_line():
     rf = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    # the kernel is VALU-issue bound: that is the roofline the top-level fraction is against; the HBM view
+    # north_star asks for sits beside it
+    assert rf["bound"] == "valu" and rf["unit"] == "Tlane-op/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0 < rf["frac"] < 1 and abs(rf["achieved"] * 1e12 - rf["cells_per_s"] * rf["ops_per_cell"]) < 1e-3 * rf["achieved"] * 1e12
+    hbm = rf["hbm"]
+    assert hbm["unit"] == "GB/s" and hbm["peak"] == 8000.0 and abs(hbm["frac"] - hbm["achieved"] / hbm["peak"]) < 1e-5 and hbm["frac"] < rf["frac"]
+    assert "traffic_over_algorithmic" in rf and set(d["scaling_definitions"]) == {"weak", "strong"}
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
@@ -52,7 +58,7 @@ def test_bench_over_rccl_on_every_gpu_the_box_has():
         g = 1
         env["SFA_DIST_FORCE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(g), "--steps", "2", "--warmup", "1", "--reads", "20000",
-                        "--no-cpu-baseline", "--no-e2e", "--check-gather"], capture_output=True, timeout=900, cwd=ROOT, env=env)
+                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
@@ -60,3 +66,10 @@ def test_bench_over_rccl_on_every_gpu_the_box_has():
     assert d["n_gpus"] == g and d["rccl_world_size"] == g and d["config"]["sharding"] == f"reads x{g}"
     assert d["gather_verified"] is True
     assert d["scaling"] == "weak" and d["value"] > 0
+    # strong scaling: one job of --total-reads reads split over the ranks by contiguous ranges (BASELINE.json configs[3] form)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(g), "--steps", "2", "--warmup", "1", "--total-reads", "30001",
+                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["total_reads"] == 30001 and sum(d["config"]["reads_per_rank"]) == 30001
+    assert d["gather_verified"] is True and abs(d["value"] - 30001 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]

@@ -25,6 +25,16 @@ def test_bench_spawns_its_own_ranks():
     assert d == {"launch_test": True, "n_gpus": 2, "world": 2}
 
 
+def test_strong_scaling_splits_one_job_over_the_ranks():
+    """--total-reads: contiguous, disjoint ranges that cover the job, whatever the remainder (two gloo ranks, no GPU)."""
+    for total, want in ((1_000_000, [[0, 500_000], [500_000, 1_000_000]]), (7, [[0, 3], [3, 7]])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--total-reads", str(total),
+                            "--workload", "r10_dna_1mb_q250"], capture_output=True, timeout=300, cwd=ROOT, env=_env(SFA_BENCH_LAUNCH_TEST="1"))
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+        assert d["scaling"] == "strong" and d["read_ranges"] == want and d["world"] == 2
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     # a launcher that produced ONE rank while --gpus says 2: an error, never a 1-GPU number under a 2-GPU label
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, timeout=300,

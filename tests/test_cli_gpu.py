@@ -122,6 +122,77 @@ def test_cli_random_signal_goldens(name, extra, models):
     assert r.stdout.decode() == open(os.path.join(GOLD, "random", name + ".out")).read()
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("name", case_names())
+def test_cli_ranks_print_the_single_process_output(name, ranks, models):
+    """`--ranks G`: the whole pipeline sharded by reads over G processes (here all on device 0), each mapping its byte slice of
+    the file, their output gathered in rank order: byte-identical to what the compiled reference printed, PAF and SAM (header
+    once), with fewer reads than ranks in some cases (empty shards)."""
+    c = load_case(name)
+    args = [str(a) for a in c["args"]]
+    cmd = [BIN, "dtw", "--kmer-model", models[c["k"]], "--verbose", "0", "--ranks", str(ranks), *args, c["fasta"], c["blow5"]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+
+
+@pytest.mark.parametrize("name", RANDOM_CASES)
+@pytest.mark.parametrize("extra", [["--ranks", "2"], ["--ranks", "3", "-K", "7"], ["--ranks", "4", "-K", "3", "--gpu-parse"],
+                                   ["--ranks", "3", "-K", "5", "--host-events"], ["--ranks", "2", "--device", "0,0", "-t", "3"]])
+def test_cli_ranks_on_random_signal_goldens(name, extra, models):
+    """40-read compressed files, ragged batches inside every rank (-K 3/5/7 against 10-20 reads per rank)."""
+    k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
+    cmd = [BIN, "dtw", "--kmer-model", models[int(k)], "--verbose", "0", *args, *extra, os.path.join(GOLD, "data", fasta),
+           os.path.join(GOLD, "random", blow5)]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == open(os.path.join(GOLD, "random", name + ".out")).read()
+
+
+@pytest.mark.parametrize("name", ["rnd_dna_sam", "rnd_rna", "rnd_dna"])
+def test_cli_shards_and_read_ranges_concatenate(name, models):
+    """What a launcher of its own would do (one process per GPU, any scheduler): `--shard r/G` per rank, `--no-header` on every
+    rank but the first, outputs concatenated in rank order; and the same with explicit record ranges."""
+    k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
+    want = open(os.path.join(GOLD, "random", name + ".out")).read()
+    base = [BIN, "dtw", "--kmer-model", models[int(k)], "--verbose", "0", *args]
+    files = [os.path.join(GOLD, "data", fasta), os.path.join(GOLD, "random", blow5)]
+
+    def run(*extra):
+        r = subprocess.run([*base, *extra, *files], capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()
+        return r.stdout.decode()
+    G = 3
+    assert "".join(run("--shard", f"{r}/{G}", *(["--no-header"] if r else [])) for r in range(G)) == want
+    cuts = [0, 1, 17, 40]
+    parts = [run("--read-range", f"{a}:{b}", *(["--no-header"] if i else [])) for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+    assert "".join(parts) == want
+    assert run("--read-range", "17:", "--no-header") == parts[2]
+    assert run("--read-range", "40:", "--no-header") == ""
+
+
+def test_cli_ranks_report_and_failures(models, tmp_path):
+    """--verbose 3: one line per rank (wall, bytes gathered) on stderr; a rank that fails makes the run fail; options that
+    contradict the sharding are refused before anything starts."""
+    import re
+    c = load_case("dna_default")
+    r = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "3", "--ranks", "2", "-t", "4", c["fasta"], c["blow5"]], capture_output=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.decode() == c["out_text"], r.stderr.decode()
+    lines = re.findall(r"\[dtw_main\] rank (\d)/2 \(device 0, 2 host threads\): done after ([0-9.]+) sec, (\d+) bytes of output gathered", r.stderr.decode())
+    assert [l[0] for l in lines] == ["0", "1"], r.stderr.decode()
+    for extra, msg in ((["--ranks", "2", "--shard", "0/2"], "cannot be combined"), (["--ranks", "2", "--read-range", "0:3"], "cannot be combined"),
+                       (["--shard", "2/2"], "0 <= r < G"), (["--read-range", "5"], "A:B"), (["--ranks", "0"], "1..64"),
+                       (["--ranks", "2", "--debug-break", "1"], "--ranks 1")):
+        bad = subprocess.run([BIN, "dtw", "--kmer-model", models[6], *extra, c["fasta"], c["blow5"]], capture_output=True, timeout=60)
+        assert bad.returncode != 0 and msg in bad.stderr.decode(), (extra, bad.stderr.decode())
+    # the second rank of two meets a file cut inside a record: the run fails as a whole
+    data = open(c["blow5"], "rb").read()
+    cut = str(tmp_path / "cut.blow5")
+    open(cut, "wb").write(data[:len(data) * 3 // 4])
+    bad = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--ranks", "2", c["fasta"], cut], capture_output=True, timeout=120)
+    assert bad.returncode != 0 and "rank of the sharded run failed" in bad.stderr.decode()
+
+
 def test_cli_errors_like_reference(models):
     c = load_case("dna_default")
     for extra, msg in ((["--dtw-std"], "only available for RNA"), (["-p", "-1"], "auto query start")):

@@ -39,5 +39,15 @@ def test_query_size_zero_is_rejected_at_parse_time():
 def test_help_lists_the_switches():
     r = subprocess.run([BIN, "dtw", "-h"], capture_output=True, timeout=60)
     assert r.returncode == 0
-    for word in ("--profile-cpu=yes|no", "--accel=yes|no", "--sam", "--kmer-model"):
+    for word in ("--profile-cpu=yes|no", "--accel=yes|no", "--sam", "--kmer-model", "--ranks", "--shard", "--read-range", "--no-header"):
         assert word in r.stdout.decode(), word
+
+
+def test_sharding_switches_are_checked_before_any_device_is_touched():
+    for extra, msg in ((["--ranks", "2", "--shard", "0/2"], "cannot be combined"), (["--shard", "3/2"], "0 <= r < G"),
+                       (["--read-range", "7:3"], "A:B"), (["--shard", "0/2", "--read-range", "1:2"], "exclude each other")):
+        r = _run(*extra)
+        assert r.returncode != 0 and msg in r.stderr.decode(), (extra, r.stderr.decode())
+    # a sharded run without a usable model: every rank fails on its own, the supervisor reports it and prints nothing
+    r = _run("--ranks", "2")
+    assert r.returncode != 0 and r.stdout == b"" and "rank of the sharded run failed" in r.stderr.decode()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end wall of the command line: raw BLOW5 -> PAF through `sigfish-amd dtw` (SURVEY.md 8d "plus end-to-end wall").
 
-    python tools/e2e_bench.py [--reads 400000] [--threads 16] [--ks 4096,512]
+    python tools/e2e_bench.py [--reads 400000] [--threads 16] [--ks 4096,512] [--ranks 2,4]
 
 Generates two files with tools/make_blow5.py from the reference's own DNA fixture replicated --reads/5 times --
 uncompressed, and zlib records + svb-zd signals (what real files look like) -- runs the command line on each at every -K
@@ -53,7 +53,53 @@ def _warm(path):
             pass
 
 
-def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), long_file=True):
+def _run_cli(model, path, threads, k, extra=(), ranks=1):
+    """One timed run of the command line (process start to exit, output to a file); returns (seconds, output path owner's dir
+    file, per-rank wall list | None)."""
+    paf = os.path.join(os.path.dirname(path), "out.paf")
+    cmd = [BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", str(k), "-B", "2G", "--verbose", "3" if ranks > 1 else "0", *extra]
+    if ranks > 1:
+        cmd += ["--ranks", str(ranks)]
+    cmd += [os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path]
+    time.sleep(PAUSE_S)
+    t0 = time.perf_counter()
+    with open(paf, "wb") as fo:
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd[1:])} failed: {r.stderr.decode()[-500:]}")
+    walls = None
+    if ranks > 1:
+        import re
+        walls = [float(x) for x in re.findall(r"\[dtw_main\] rank \d+/\d+ \([^)]*\): done after ([0-9.]+) sec", r.stderr.decode())]
+        if len(walls) != ranks:
+            raise RuntimeError(f"expected {ranks} rank lines on stderr, found {len(walls)}")
+    return dt, paf, walls
+
+
+def _check_rows(paf, copies, want_head, what):
+    n, ok = 0, True
+    with open(paf) as fi:
+        for i, line in enumerate(fi):
+            n += 1
+            if i < 5:  # first copy of the fixture's reads: same rows as the fixture, read ids carry the copy suffix
+                a, b = line.rstrip("\n").split("\t"), want_head[i].split("\t")
+                ok = ok and a[0] == b[0] + "_0" and a[1:] == b[1:]
+    if n != copies * 5 or not ok:
+        raise RuntimeError(f"end-to-end output differs from the fixture on {what} ({n} rows)")
+    return n
+
+
+def _sha(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), long_file=True, ranks=(2,)):
     where = "given directory"
     d = keep_dir
     if d is None:
@@ -61,7 +107,10 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
     out = {"unit": "reads/s", "reads": 0, "host_threads": threads, "files_in": where,
            "page_cache": "warm: every generated file is synced and read once before its first timed run",
            "pause_before_each_run_s": PAUSE_S,
-           "what": "raw BLOW5 -> PAF through `sigfish-amd dtw` (process start to exit), reference's DNA fixture replicated, nCoV reference"}
+           "what": "raw BLOW5 -> PAF through `sigfish-amd dtw` (process start to exit), reference's DNA fixture replicated, nCoV reference",
+           "ranks": "keys ending in _ranksG: the same command with --ranks G -- G processes on ONE GPU here, each mapping its byte "
+                    "slice of the file with host_threads/G threads, output gathered in rank order and compared (sha256) with the "
+                    "one-process output; rank_wall_s = seconds from the supervisor's start to each rank's exit"}
     try:
         lv = np.fromfile(os.path.join(GOLD, "models", "syn6.f32"), np.float32)
         model = os.path.join(d, "syn6.model")
@@ -71,46 +120,36 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
                 f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
         copies = max(reads // 5, 1)
         want_head = open(os.path.join(GOLD, "cases", "dna_default.out")).read().splitlines()
+
+        def sharded(path, k, key, n_copies, one_rank_sha):
+            for g in ranks:
+                dt, paf, walls = _run_cli(model, path, threads, k, extra, ranks=g)
+                n = _check_rows(paf, n_copies, want_head, f"{key} with --ranks {g}")
+                if _sha(paf) != one_rank_sha:
+                    raise RuntimeError(f"--ranks {g} output differs from the one-process output on {key}")
+                out[f"{key}_ranks{g}"] = round(n / dt, 1)
+                out[f"{key}_ranks{g}_rank_wall_s"] = walls
+
         for kind, flags in (("uncompressed", []), ("compressed", ["--compress"])):
             path = os.path.join(d, kind + ".blow5")
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
                             "--copies", str(copies), "--jobs", str(min(threads, 16)), *flags], check=True, capture_output=True)
             out[kind + "_file_MB"] = round(os.path.getsize(path) / 1e6, 1)
             _warm(path)
+            sha = None
             for k in ks:
-                paf = os.path.join(d, "out.paf")
-                time.sleep(PAUSE_S)
-                t0 = time.perf_counter()
-                with open(paf, "wb") as fo:
-                    r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", str(k), "-B", "2G", "--verbose", "0", *extra,
-                                        os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path], stdout=fo, stderr=subprocess.PIPE)
-                dt = time.perf_counter() - t0
-                if r.returncode != 0:
-                    raise RuntimeError(f"sigfish-amd dtw failed on the {kind} file at -K {k}: {r.stderr.decode()[-500:]}")
-                n = 0
-                ok = True
-                with open(paf) as fi:
-                    for i, line in enumerate(fi):
-                        n += 1
-                        if i < 5:  # first copy of the fixture's reads: same rows as the fixture, read ids carry the copy suffix
-                            a, b = line.rstrip("\n").split("\t"), want_head[i].split("\t")
-                            ok = ok and a[0] == b[0] + "_0" and a[1:] == b[1:]
-                if n != copies * 5 or not ok:
-                    raise RuntimeError(f"end-to-end output differs from the fixture on the {kind} file at -K {k} ({n} rows)")
+                dt, paf, _ = _run_cli(model, path, threads, k, extra)
+                n = _check_rows(paf, copies, want_head, f"the {kind} file at -K {k}")
                 out["reads"] = n
                 out[f"{kind}_K{k}"] = round(n / dt, 1)
-            if kind == "compressed":  # the same file with the records decompressed and parsed on the device (sfa_align_blow5)
-                time.sleep(PAUSE_S)
-                t0 = time.perf_counter()
-                with open(os.path.join(d, "out.paf"), "wb") as fo:
-                    r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", "8192", "-B", "2G", "--verbose", "0",
-                                        "--gpu-parse", "--streams", "4", os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path],
-                                       stdout=fo, stderr=subprocess.PIPE)
-                dt = time.perf_counter() - t0
-                rows = sum(1 for _ in open(os.path.join(d, "out.paf")))
-                if r.returncode != 0 or rows != copies * 5:
-                    raise RuntimeError(f"sigfish-amd dtw --gpu-parse failed on the compressed file: {r.stderr.decode()[-300:]}")
-                out["compressed_gpu_parse_K8192_streams4"] = round(rows / dt, 1)
+                if k == ks[0]:
+                    sha = _sha(paf)
+            if kind == "compressed":
+                sharded(path, ks[0], f"compressed_K{ks[0]}", copies, sha)
+                # the same file with the records decompressed and parsed on the device (sfa_align_blow5)
+                dt, paf, _ = _run_cli(model, path, threads, 8192, ["--gpu-parse", "--streams", "4"])
+                n = _check_rows(paf, copies, want_head, "the compressed file with --gpu-parse")
+                out["compressed_gpu_parse_K8192_streams4"] = round(n / dt, 1)
             os.remove(path)
         # ... and a file four times as long (real files hold millions of reads): what a process costs besides its reads -- HIP
         # runtime, code objects, contexts, exit: 0.3-0.4 s -- is 40 % of a 400 000-read run and 15 % of this one
@@ -125,20 +164,14 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
                             "--copies", str(long_copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True)
             _warm(path)
-            time.sleep(PAUSE_S)
-            t0 = time.perf_counter()
-            with open(os.path.join(d, "out.paf"), "wb") as fo:
-                r = subprocess.run([BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", "4096", "-B", "2G", "--verbose", "0", *extra,
-                                    os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path], stdout=fo, stderr=subprocess.PIPE)
-            dt = time.perf_counter() - t0
-            rows = sum(1 for _ in open(os.path.join(d, "out.paf")))
-            if r.returncode != 0 or rows != long_copies * 5:
-                raise RuntimeError(f"sigfish-amd dtw failed on the long compressed file: {r.stderr.decode()[-300:]}")
+            dt, paf, _ = _run_cli(model, path, threads, 4096, extra)
+            rows = _check_rows(paf, long_copies, want_head, "the long compressed file")
             out["long_file_reads"] = rows
             out["long_file_MB"] = round(os.path.getsize(path) / 1e6, 1)
             out["compressed_K4096_long_file"] = round(rows / dt, 1)
+            sharded(path, 4096, "compressed_K4096_long_file", long_copies, _sha(paf))
             os.remove(path)
-        out["parity"] = "row count and the first five rows (= the reference's PAF for the fixture) checked in every run"
+        out["parity"] = "row count and the first five rows (= the reference's PAF for the fixture) checked in every run; sharded runs byte-identical to the one-process run"
     finally:
         if not keep_dir:
             shutil.rmtree(d, ignore_errors=True)
@@ -151,6 +184,8 @@ if __name__ == "__main__":
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--ks", default="4096,512")
     ap.add_argument("--no-long-file", action="store_true", help="skip the run on a file four times as long")
+    ap.add_argument("--ranks", default="2", help="comma separated --ranks values for the sharded runs (empty: none)")
     ap.add_argument("extra", nargs="*")
     a = ap.parse_args()
-    print(json.dumps(measure(a.reads, a.threads, tuple(int(k) for k in a.ks.split(",")), extra=a.extra, long_file=not a.no_long_file)))
+    print(json.dumps(measure(a.reads, a.threads, tuple(int(k) for k in a.ks.split(",")), extra=a.extra, long_file=not a.no_long_file,
+                             ranks=tuple(int(g) for g in a.ranks.split(",") if g))))
