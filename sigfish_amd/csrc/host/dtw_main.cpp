@@ -407,7 +407,8 @@ static int dtw_run(int argc, char **argv) {
                 char *e = nullptr;
                 o.range_a = strtoll(optarg, &e, 10);
                 if (e == optarg || *e != ':' || o.range_a < 0) die("--read-range takes A:B (records A up to, not including, B; B may be omitted)");
-                o.range_b = e[1] ? strtoll(e + 1, &e, 10) : -1;
+                ++e;  // past the colon
+                o.range_b = *e ? strtoll(e, &e, 10) : -1;
                 if (*e || (o.range_b >= 0 && o.range_b < o.range_a)) die("--read-range takes A:B (records A up to, not including, B; B may be omitted)");
                 break;
             }
