@@ -106,7 +106,7 @@ typedef struct {
     int64_t blow5_fallbacks; /* batches of this context handed to the host reader because the device declined a record */
     int64_t lds_ckpt;      /* 1: the fill kept its rolling checkpoints in LDS (ckpt_interval is then the sparse HBM store's);
                               2: and pass 2 ran inside the fill launch (fill_ms covers both, trace_ms is 0) */
-    int64_t trace_margin;  /* head start of pass 2 in steps (a whole query + lanes, or less: "adaptive_margin") */
+    int64_t trace_margin;  /* head start of pass 2 in steps (a whole query + lanes, or less: see "trace_margin") */
 } sfa_profile_t;
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */
@@ -168,39 +168,44 @@ int sfa_wait_batch(sfa_ctx_t *ctx, sfa_result_t *out, int32_t n_reads);
 int sfa_align_events(sfa_ctx_t *ctx, const sfa_event_t *const *events, const int64_t *n_events,
                      const int64_t *qstart, const int64_t *qend, int32_t n_reads, sfa_result_t *out);
 
-/* Tuning knobs (all optional): "single_pass" (0/1: track start columns in one pass instead of fill + trace),
- * "ckpt_interval" (0 = auto, else a power of two >= 4), "ckpt_budget_bytes", "trace_margin" (-1 = qlen+16),
- * "lds_ckpt" (1 = default: where every shape of the batch has <= 16 rows per lane, the fill keeps its last two snapshots in
- * LDS and writes one to HBM only when a window becomes a read's best so far, plus a sparse store every 32768 steps for pass 2
- * to back off to -- with --dtw-std, whose single candidate per contig is its last cell, no snapshots at all but the sparse
- * store; 2 = the same whatever the batch size, and queries of 257..1024 events run as 16-row shapes (32 / 64 lanes per
- * read) on that route instead of the 32-row kernels; 0 = every snapshot to HBM), "mixed_quads" (1 = default: reads whose
- * lengths agree modulo the rows per lane of their class share a wavefront; 0 = one length per wavefront),
- * "adaptive_margin" (1 = default: where the snapshots of pass 1 are in HBM -- queries beyond 256 events -- pass 2 of a batch
- * starts as far in front of the winning cell as 99.9 % of the PREVIOUS batch's alignments spanned (+ 1/8 query + lanes + 16)
- * instead of a whole query length; a read whose path is longer backs off one snapshot; 0 = always a whole query length),
- * "spin_limit_ms" (default 20000: the longest a wave of a launch waits for another wave of the same launch -- pass 2 for its
- * quad's fill tasks, a row strip for the strip above -- before the batch fails with SFA_EKERNEL; never less than about
- * five times the longest fill task), "debug_drop_quad" / "debug_drop_strip" (test hooks for that bound: the producer
- * with this index skips its signal; -1 = off), "prio_unit" (columns per step of
- * the fill's longest-remaining-first issue priority in the tail of a launch; 0 = off), "fused_trace" (with "lds_ckpt": 1 =
- * default: pass 2 runs inside the fill launch when the launch has more wave-tasks than the device has wave slots, 2 =
- * always, 0 = always as its own launch), "strip_pipeline" (long queries: 1 = default, the row strips of pass 1 run as one
- * pipelined launch; 0 = one wave per (read, contig, strand)), "strip_chain" (long queries: 1 = default, pass 2 traces the
- * strips from the last one upwards, each over its own short range of columns; 0 = all strips over the whole range),
- * "balanced_strips" (long queries: 1 = default, the strips of a query have equal height, 64 lanes x {20, 24, 28, 32} rows
- * by query length; 0 = 64 x 32 rows and a short last strip), "long_overlap" (1 = default: the row strips of a batch's long
- * queries run on their own stream beside the wave kernels of its other reads; 0 = behind them),
- * "waves_per_simd" (1..8, occupancy target used when splitting the contig list), "lane_widening" (0 = auto by batch
- * size, 1/2/4 = fixed: rows per lane / w and lanes per read * w, the small-batch latency shapes), "widen_below"
- * (auto mode widens x4 when the batch has fewer waves per SIMD than this; default 5), "min_slice_reads" (a batch whose
- * checkpoints would not fit the budget at the shortest interval is cut into slices of at least this many reads, run
- * back to back; default 65536), "ev_parallel_prefix" (sfa_align_raw: 1 = wave-per-read prefix sums for every read
- * whose sums are provably exact in any order, the sequential kernel for the rest; 0 = sequential for all),
- * "column_segments" (0 = auto: small batches cut every (contig,strand) sweep into up to 64 verified segments, 1 = off,
- * 2..64 = that many), "segment_warm_windows" (query lengths a segment starts early; default 4),
- * "ev_parallel_peaks" (the same for the peak picker: 1 = chunk-parallel walk accepted where it is certified to equal the
- * sequential one). */
+/* Options (all optional; rows never depend on them -- every setting is held to the same parity tests).  14 keys:
+ *   planner
+ *     "lane_widening"         0 = auto by batch size (default); 1 / 2 / 4 = fixed: rows per lane / w and lanes per read * w -- the
+ *                             small-batch latency shapes
+ *     "widen_below"           auto mode widens x4 when a batch has fewer wave-tasks per SIMD than this (default 5; a caller with
+ *                             several batches in flight per device lowers it)
+ *     "column_segments"       0 = auto (small batches cut every (contig,strand) sweep into up to 64 verified segments), 1 = off,
+ *                             2..64 = that many
+ *     "segment_warm_windows"  query lengths a segment starts early (default 4)
+ *     "waves_per_simd"        1..8, occupancy target used when splitting the contig list into chunks (default 6)
+ *     "min_slice_reads"       a batch whose checkpoints would not fit the budget at the shortest interval is cut into slices of at
+ *                             least this many reads, run back to back (default 65536)
+ *   pass 1 -> pass 2 hand-over
+ *     "lds_ckpt"              1 = default: where every shape of the batch has <= 16 rows per lane (queries up to 256 events) the fill
+ *                             keeps its last two snapshots in LDS and writes one to HBM only when a window becomes a read's best so
+ *                             far, plus a sparse store every 32768 steps for pass 2 to back off to (--dtw-std: the sparse store
+ *                             alone); 2 = the same whatever the batch size and up to 1024 events at 16 rows per lane; 0 = every
+ *                             snapshot to HBM.  Shapes with 32 rows per lane always keep their snapshots in HBM.
+ *     "fused_trace"           1 = default: pass 2 runs inside the fill launch (tickets) when the launch has more wave-tasks than the
+ *                             device has wave slots; 2 = always; 0 = always as its own launch
+ *     "ckpt_interval"         0 = auto, else a power of two >= 4: snapshots of pass 1 in HBM every that many steps
+ *     "ckpt_budget_bytes"     HBM the snapshots of one batch may take (default 32 GiB)
+ *     "trace_margin"          -1 = auto: pass 2 starts a query length (+ lanes) in front of the winning window -- on the HBM-snapshot
+ *                             route as far as 99.9 % of the PREVIOUS batch's alignments spanned, rounded up to the next sixteenth of
+ *                             the query, + 1/16 query + lanes + 16; a read whose path is longer backs off one snapshot; >= 0: that
+ *                             many steps
+ *   launch
+ *     "prio_unit"             columns per level of the fill's longest-remaining-first issue priority in the tail of a launch
+ *                             (default 2048; 0 = off)
+ *     "spin_limit_ms"         default 20000: the longest a wave of a launch waits for another wave of the same launch -- pass 2 for
+ *                             its quad's fill tasks, a row strip for the strip above -- before the batch fails with SFA_EKERNEL;
+ *                             floors apply (about five times the longest fill task; the strips' pipeline depth)
+ *   raw-signal path
+ *     "ev_parallel"           bit 0: wave-per-read prefix sums for every read whose sums are provably exact in any order (the
+ *                             sequential kernel for the rest); bit 1: chunk-parallel peak picker accepted where it is certified
+ *                             to equal the sequential one; default 3
+ * Test hooks, refused unless SFA_TEST_HOOKS=1 is in the environment: "debug_drop_quad" / "debug_drop_strip" (the producer with
+ * this index never signals; every batch then fails with SFA_EKERNEL after the wait limit; -1 = off). */
 int sfa_set_option(sfa_ctx_t *ctx, const char *key, int64_t value);
 
 /* Plan a batch without running it: how reads would be grouped.  slot_of_read[n_reads] (may be NULL) receives

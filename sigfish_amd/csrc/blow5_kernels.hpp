@@ -329,7 +329,7 @@ __device__ inline int inflate_zlib_lane(const uint8_t *in, int64_t n_in, uint8_t
     return static_cast<int>(op);
 }
 
-#ifdef SFA_DEFINE_FINALIZE_KERNEL  // plain kernels: defined in exactly one translation unit
+#ifdef SFA_DEFINE_BLOW5_KERNELS  // plain kernels: defined in exactly one translation unit (sfa_pre.hip)
 // `lanes` records per wave (one wave per block, the other lanes idle), chosen by the host from the batch size
 // (inflate_lanes()).  A wave of independent decoders executes every lane's path: whenever ONE lane meets a code longer than
 // the first-level table, a match or a block header, all of them sit through it -- with 32 records per wave that is nearly

@@ -450,31 +450,6 @@ void Blow5Reader::parse_pair(const uint8_t *const mem[2], const size_t size[2], 
     parse_blow5_record_pair(mem, size, record_press_ == 1, signal_press_ == 1, rec, err, ok);
 }
 
-bool Blow5Reader::inflate_record(const uint8_t *mem, size_t size, std::vector<uint8_t> *out, size_t *len) const {
-    if (record_press_ != 1) {
-        if (out->size() < size) out->resize(size);
-        if (size) memcpy(out->data(), mem, size);
-        *len = size;
-        return true;
-    }
-    if (fast_inflate_zlib(mem, size, out, len)) return true;
-    const uint8_t *p = nullptr;  // declined by the own decoder: zlib's inflate has the last word (this thread's buffer)
-    if (!inflate_all(mem, size, &p, len)) return false;
-    if (out->size() < *len) out->resize(*len);
-    if (*len) memcpy(out->data(), p, *len);
-    return true;
-}
-
-void Blow5Reader::inflate_pair(const uint8_t *const mem[2], const size_t size[2], std::vector<uint8_t> *const out[2], size_t len[2], bool ok[2]) const {
-    if (record_press_ != 1) {
-        for (int k = 0; k < 2; ++k) ok[k] = inflate_record(mem[k], size[k], out[k], &len[k]);
-        return;
-    }
-    fast_inflate_zlib_pair(mem, size, out, len, ok);
-    for (int k = 0; k < 2; ++k)
-        if (!ok[k]) ok[k] = inflate_record(mem[k], size[k], out[k], &len[k]);  // (own decoder alone, then zlib)
-}
-
 int Blow5Reader::next(Blow5Record *rec) {
     if (map_) {  // one position per reader: the iterator that a selection walked is the one that reads on
         const uint8_t *mem;

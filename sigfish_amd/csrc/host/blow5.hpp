@@ -51,11 +51,6 @@ class Blow5Reader {
     int next_view(const uint8_t **mem, size_t *size);
     bool parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const;
     void parse_pair(const uint8_t *const mem[2], const size_t size[2], Blow5Record *const rec[2], std::string *const err[2], bool ok[2]) const;
-    // only the record decompression: the inflated payload of one record / of two records side by side into the callers' buffers
-    // (grown as needed; *len bytes are valid).  For callers that hand the payloads on to the device-side parser
-    // (sfa_align_blow5 with record_zlib = 0).  Files without record compression: the record is its own payload (copied).
-    bool inflate_record(const uint8_t *mem, size_t size, std::vector<uint8_t> *out, size_t *len) const;
-    void inflate_pair(const uint8_t *const mem[2], const size_t size[2], std::vector<uint8_t> *const out[2], size_t len[2], bool ok[2]) const;
     // first value (read group 0) of a header attribute, or nullptr (slow5_hdr_get(attr, 0, hdr))
     const char *attr(const std::string &key) const;
     uint32_t num_read_groups() const { return n_groups_; }

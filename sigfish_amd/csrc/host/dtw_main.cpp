@@ -49,8 +49,6 @@ struct Opt {
     std::vector<int> devices{0};  // --device 0,1,...: batches go to the devices in turn
     bool host_events = false;  // --host-events: event detection on host threads instead of the GPU
     int gpu_parse = -1;        // --gpu-parse / --host-parse: records decompressed and parsed on the GPU / on host threads (-1: by device count)
-    int host_inflate = 0;      // --host-inflate: compressed records are inflated on host threads and parsed + decoded on the GPU
-    int hybrid_every = -1;     // --hybrid-parse N: every Nth batch goes to the device as it is in the file, the others through host threads (0: off, -1: auto)
     int streams = 0;           // --streams: device contexts that take batches in turn (0 = 2)
     // read sharding over processes (one per GPU): what part of the file THIS process maps
     int ranks = 0;                       // --ranks G: start G processes on disjoint parts of the file, print their output in rank order (0: one per distinct device)
@@ -109,7 +107,7 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   -h                         help\n   -o FILE                    output to file [stdout]\n");
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n   --version                  print version\n", o.verbosity);
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
-    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs, GPU beyond]\n   --host-inflate             inflate the records on host threads, parse and decode them on the GPU [off]\n   --hybrid-parse INT         every INTth batch is decompressed and parsed on the GPU, the others on host threads; 0 = off [0]\n   --streams INT              device contexts taking batches in turn [2]\n");
+    fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs per process, GPU beyond]\n   --streams INT              device contexts taking batches in turn [2]\n");
     fprintf(fp, "   --ranks INT                read-shard the run over INT processes (rank r: device r of the list, -t/INT threads, the r-th\n"
                 "                              byte slice of the file); output is printed in rank order = file order [one per distinct device]\n"
                 "   --shard r/G                map only the records starting in the r-th of G equal byte slices of the file\n"
@@ -134,8 +132,6 @@ struct Read {
     const uint8_t *view = nullptr;     // record bytes inside the mapped file otherwise
     size_t view_size = 0;
     sfa::Blow5Record rec;
-    std::vector<uint8_t> payload;      // --host-inflate: the record's inflated bytes (payload_len of them), parsed on the device
-    size_t payload_len = 0;
     std::vector<sfa_event_t> ev;
     std::vector<float> pa;             // --profile-cpu=yes: picoamps kept between the events and the normalise stage
     int64_t qstart = 0, qend = 0;
@@ -337,7 +333,7 @@ static int dtw_run(int argc, char **argv) {
                           {"profile-cpu", required_argument, 0, 8}, {"accel", required_argument, 0, 9},
                           {"sam", no_argument, 0, 'a'},             {"pore", required_argument, 0, 10},
                           {"device", required_argument, 0, 11},     {"secondary", required_argument, 0, 12},
-                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   {"hybrid-parse", required_argument, 0, 18},   {"host-inflate", no_argument, 0, 19},
+                          {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   
                           {"ranks", required_argument, 0, 20},      {"shard", required_argument, 0, 21},
                           {"read-range", required_argument, 0, 22}, {"no-header", no_argument, 0, 23},
                           {0, 0, 0, 0}};
@@ -393,11 +389,6 @@ static int dtw_run(int argc, char **argv) {
             case 14: o.host_events = true; break;
             case 16: o.gpu_parse = 0; break;
             case 17: o.gpu_parse = 1; break;
-            case 19: o.host_inflate = 1; break;
-            case 18:
-                o.hybrid_every = atoi(optarg);
-                if (o.hybrid_every < 0 || o.hybrid_every == 1) die("--hybrid-parse takes 0 (off) or an integer >= 2 (use --gpu-parse for every batch)");
-                break;
             case 20: o.ranks = atoi(optarg); if (o.ranks < 1 || o.ranks > 64) die("--ranks should be 1..64"); break;
             case 21:
                 if (sscanf(optarg, "%d/%d", &o.shard_r, &o.shard_n) != 2 || o.shard_n < 1 || o.shard_r < 0 || o.shard_r >= o.shard_n)
@@ -452,11 +443,17 @@ static int dtw_run(int argc, char **argv) {
     double ti = realtime();
     sfa::Blow5Reader reader;
     if (!reader.open(blow5)) die(reader.error());
-    if (o.shard_n > 1 && !reader.select_shard(static_cast<uint32_t>(o.shard_r), static_cast<uint32_t>(o.shard_n))) die(reader.error());
-    if ((o.range_a > 0 || o.range_b >= 0) &&
-        !reader.select_records(static_cast<uint64_t>(o.range_a), o.range_b < 0 ? UINT64_MAX : static_cast<uint64_t>(o.range_b - o.range_a)))
-        die(reader.error());
-    reader.start_prefault();  // a helper thread takes the page faults of the mapped file ahead of the batch loop (blow5.hpp)
+    // This process's part of the file.  Finding it means walking the size prefixes of every record in front of it (0.36 us each: 0.3 s
+    // for the second half of a 1.6 M-read file), which needs nothing but the mapping: a helper thread does it while this one reads
+    // the model, builds the reference events and brings up the device contexts (0.3-0.4 s).  Joined in front of the batch loop.
+    std::future<bool> selected = std::async(std::launch::async, [&reader, &o] {
+        if (o.shard_n > 1 && !reader.select_shard(static_cast<uint32_t>(o.shard_r), static_cast<uint32_t>(o.shard_n))) return false;
+        if ((o.range_a > 0 || o.range_b >= 0) &&
+            !reader.select_records(static_cast<uint64_t>(o.range_a), o.range_b < 0 ? UINT64_MAX : static_cast<uint64_t>(o.range_b - o.range_a)))
+            return false;
+        reader.start_prefault();  // a helper thread takes the page faults of the mapped file ahead of the batch loop (blow5.hpp)
+        return true;
+    });
     t_init[0] = realtime() - ti;
     ti = realtime();
     if (const char *exp = reader.attr("experiment_type")) {
@@ -525,7 +522,7 @@ static int dtw_run(int argc, char **argv) {
         const int per_dev = n_ctx / static_cast<int>(o.devices.size());
         if (sfa_set_option(ctxs[j], "widen_below", std::max(1, 5 / per_dev)) != SFA_OK) die(sfa_last_error());
         // SFA_OPTS="name=value,name=value": planner / launch options of the library (sfa_set_option) for experiments from the
-        // command line (tools/e2e_env_ab.sh); rows do not depend on them
+        // command line; rows do not depend on them (the library's test hooks are not options: refused here whatever the environment)
         if (const char *e = getenv("SFA_OPTS")) {
             std::string all(e);
             for (size_t p = 0; p < all.size();) {
@@ -533,6 +530,7 @@ static int dtw_run(int argc, char **argv) {
                 const std::string kv = all.substr(p, q - p);
                 const size_t eq = kv.find('=');
                 if (eq == std::string::npos || eq == 0) die("SFA_OPTS takes name=value[,name=value...]");
+                if (kv.compare(0, 6, "debug_") == 0) die("SFA_OPTS: '" + kv.substr(0, eq) + "' is a test hook of the library, not an option");
                 if (sfa_set_option(ctxs[j], kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)) != SFA_OK) die(std::string("SFA_OPTS: ") + sfa_last_error());
                 p = q + 1;
             }
@@ -540,6 +538,10 @@ static int dtw_run(int argc, char **argv) {
     }
 
     t_init[2] = realtime() - ti;
+    ti = realtime();
+    if (!selected.get()) die(reader.error());
+    const double t_select = realtime() - ti;  // what of the walk the initialisation did not hide
+    if (o.verbosity >= 4 && (o.shard_n > 1 || o.range_a > 0)) fprintf(stderr, "[dtw_main::%.3f] waited %.3f s more for this process's part of the file\n", realtime() - t0, t_select);
     if (o.verbosity >= 4)
         fprintf(stderr, "[dtw_main::%.3f] initialised: input %.3f s, model + reference events %.3f s, %d device context(s) %.3f s\n", realtime() - t0,
                 t_init[0], t_init[1], n_ctx, t_init[2]);
@@ -581,7 +583,6 @@ static int dtw_run(int argc, char **argv) {
         int32_t n = 0;
         int64_t bytes = 0;
         bool via_device = false;  // this batch's records go to the device as they are in the file (sfa_align_blow5)
-        bool inflated = false;    // ... after the host threads have inflated them (the device parses fields and decodes signals)
     };
     // events on the GPU unless the RNA auto prefix is asked for (adaptor/poly-A detection stays on the host); for SAM the
     // event tables of the query windows come back from the device with the rows
@@ -593,22 +594,6 @@ static int dtw_run(int argc, char **argv) {
     // LDS -- and the host route is the better one at the default -K 4096.  What the device route buys is independence from the
     // host: a node's cores do not grow with its GPUs, so it is the default from three devices on.
     const bool gpu_parse = gpu_events && (o.gpu_parse < 0 ? o.devices.size() > 2 : o.gpu_parse == 1);
-    // ... or some of them (round 3, --hybrid-parse N): every Nth batch on the device route, the others on the host route -- the two
-    // routes load different resources.  While the host stage was the limit (27 us of inflate per record and core) that paid:
-    // whole process on a compressed 400 000-read file 0.32 M reads/s host route, 0.36 / 0.37 / 0.39 M with every 4th / 3rd / 2nd
-    // batch on the device (profiles/r03_logs/e2e_bench_before_paired_inflate_hybrid4.json and its neighbours).  Since the host
-    // threads inflate two records side by side and a helper takes the mapping's page faults, the host stage (0.44 s for that
-    // file) is level with the device's stages (0.88 s over two contexts), and handing batches to the device only moves the limit
-    // there: 0.43 M host route, 0.39-0.42 M with every 6th / 4th batch (e2e_prefault_and_hybrid_400k.log).  Off unless asked for.
-    const int hybrid_every = (!gpu_events || gpu_parse || o.gpu_parse == 0 || prf) ? 0 : (o.hybrid_every >= 0 ? o.hybrid_every : 0);
-    // ... or the work of ONE record is split (round 3, --host-inflate): the host threads do the serial bit stream of DEFLATE, two
-    // records side by side per thread, and hand the inflated payloads to the device, which parses the fields and decodes the
-    // StreamVByte signals (sfa_align_blow5 with record_zlib = 0) before it detects events and aligns.  Measured and NOT the
-    // default (profiles/r03_logs/rejected_host_inflate_device_parse_route.log, compressed 400 000-read file, whole process): the
-    // host stage only falls from 0.414 to 0.386 s -- inflating is 15 of the 18 us a record costs a host thread -- while the device
-    // stage grows from 0.77 to 0.84 s (two more host round trips per batch on the record route): 0.36-0.40 M reads/s against
-    // 0.43-0.49 M for the host route and 0.32-0.37 M for the device route.
-    const bool host_inflate = gpu_events && !gpu_parse && !prf && reader.records_zlib() && o.host_inflate == 1;
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);
@@ -629,7 +614,7 @@ static int dtw_run(int argc, char **argv) {
             sl.info.resize(n);
             sl.heads.resize(n);
             if (sam) sl.qev.resize(static_cast<size_t>(n) * o.query);
-            if (n > 0 && sfa_align_blow5(ctx, sl.rec_bytes, sl.rec_off.data(), n, sl.inflated ? 0 : reader.records_zlib(), reader.signal_svb(), o.prefix, o.query,
+            if (n > 0 && sfa_align_blow5(ctx, sl.rec_bytes, sl.rec_off.data(), n, reader.records_zlib(), reader.signal_svb(), o.prefix, o.query,
                                          rows.data(), sl.info.data(), sl.heads.data(), sam ? sl.qev.data() : nullptr) != SFA_OK)
                 die(std::string("alignment failed: ") + sfa_last_error());
         } else if (gpu_events) {
@@ -748,8 +733,7 @@ static int dtw_run(int argc, char **argv) {
         }
         sl.n = n;
         sl.bytes = bytes;
-        sl.via_device = gpu_parse || host_inflate || (hybrid_every > 0 && bi % hybrid_every == hybrid_every - 1);
-        sl.inflated = host_inflate;
+        sl.via_device = gpu_parse;
         t_load += realtime() - a;
         if (o.verbosity >= 4)
             fprintf(stderr, "[dtw_main::%.3f*%.2f] %d Entries (%.1fM bytes) loaded\n", realtime() - t0, cputime() / (realtime() - t0), n, bytes / 1e6);
@@ -776,31 +760,11 @@ static int dtw_run(int argc, char **argv) {
                 r.keep = sfa::select_and_normalise(r.ev, r.rec.raw.data(), static_cast<int64_t>(r.rec.raw.size()), pa.data(), o.prefix, o.query,
                                                    o.flag, o.pore_flag, &r.qstart, &r.qend, &r.status);
         };
-        if (sl.via_device) {  // nothing to parse here: the records go to the device as they are -- or inflated, two per thread
+        if (sl.via_device) {  // nothing to parse here: the records go to the device as they are
             double b = realtime();
-            if (sl.inflated) {
-                pool.run((n + 1) / 2, [&](int64_t j) {
-                    const int64_t i0 = 2 * j, i1 = std::min<int64_t>(2 * j + 1, n - 1);
-                    Read &a0 = batch[i0], &a1 = batch[i1];
-                    if (i1 == i0) {
-                        if (!reader.inflate_record(a0.view ? a0.view : a0.mem.data(), a0.view_size, &a0.payload, &a0.payload_len)) bad = 1;
-                        return;
-                    }
-                    const uint8_t *const mem[2] = {a0.view ? a0.view : a0.mem.data(), a1.view ? a1.view : a1.mem.data()};
-                    const size_t size[2] = {a0.view_size, a1.view_size};
-                    std::vector<uint8_t> *const out[2] = {&a0.payload, &a1.payload};
-                    size_t len[2] = {0, 0};
-                    bool ok[2];
-                    reader.inflate_pair(mem, size, out, len, ok);
-                    a0.payload_len = len[0];
-                    a1.payload_len = len[1];
-                    if (!ok[0] || !ok[1]) bad = 1;
-                });
-                if (bad) die("malformed BLOW5: record does not inflate");
-            }
             sl.rec_off.resize(n + 1);
             sl.rec_off[0] = 0;
-            for (int32_t i = 0; i < n; ++i) sl.rec_off[i + 1] = sl.rec_off[i] + static_cast<int64_t>(sl.inflated ? batch[i].payload_len : batch[i].view_size);
+            for (int32_t i = 0; i < n; ++i) sl.rec_off[i + 1] = sl.rec_off[i] + static_cast<int64_t>(batch[i].view_size);
             const size_t need = static_cast<size_t>(sl.rec_off[n]) + 64;
             if (need > sl.rec_cap) {
                 sfa_pinned_free(sl.rec_bytes);
@@ -809,7 +773,7 @@ static int dtw_run(int argc, char **argv) {
                 if (!sl.rec_bytes) die(std::string("cannot allocate the record staging buffer: ") + sfa_last_error());
             }
             pool.run(n, [&](int64_t i) {
-                const uint8_t *src = sl.inflated ? batch[i].payload.data() : (batch[i].view ? batch[i].view : batch[i].mem.data());
+                const uint8_t *src = batch[i].view ? batch[i].view : batch[i].mem.data();
                 memcpy(sl.rec_bytes + sl.rec_off[i], src, static_cast<size_t>(sl.rec_off[i + 1] - sl.rec_off[i]));
             });
             t_parse += realtime() - b;

@@ -2,5 +2,5 @@
 #include "sdtw_kernels.hpp"
 
 namespace sfa {
-template __global__ void sdtw_fill_kernel<32, false, false>(const DpArgs);
+template __global__ void sdtw_fill_kernel<32, false>(const DpArgs);
 }  // namespace sfa

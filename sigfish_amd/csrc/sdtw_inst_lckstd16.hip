@@ -3,12 +3,12 @@
 #include "sdtw_kernels.hpp"
 
 namespace sfa {
-template __global__ void sdtw_fill_kernel<16, false, true, false, true>(const DpArgs);
-template __global__ void sdtw_fill_kernel<8, false, true, false, true>(const DpArgs);
-template __global__ void sdtw_fill_kernel<4, false, true, false, true>(const DpArgs);
-template __global__ void sdtw_fill_kernel<16, false, true, false, true, true>(const DpArgs);
-template __global__ void sdtw_fill_kernel<8, false, true, false, true, true>(const DpArgs);
-template __global__ void sdtw_fill_kernel<4, false, true, false, true, true>(const DpArgs);
+template __global__ void sdtw_fill_kernel<16, true, false, true>(const DpArgs);
+template __global__ void sdtw_fill_kernel<8, true, false, true>(const DpArgs);
+template __global__ void sdtw_fill_kernel<4, true, false, true>(const DpArgs);
+template __global__ void sdtw_fill_kernel<16, true, false, true, true>(const DpArgs);
+template __global__ void sdtw_fill_kernel<8, true, false, true, true>(const DpArgs);
+template __global__ void sdtw_fill_kernel<4, true, false, true, true>(const DpArgs);
 template __global__ void sdtw_trace_kernel<16, true, true>(const DpArgs, int32_t *);
 template __global__ void sdtw_trace_kernel<8, true, true>(const DpArgs, int32_t *);
 template __global__ void sdtw_trace_kernel<4, true, true>(const DpArgs, int32_t *);

@@ -56,19 +56,11 @@ constexpr int kRefPad = 128;       // floats of +inf padding on both sides of ev
 #ifndef SFA_LCK_WAVES
 #define SFA_LCK_WAVES 4  // the fill with its checkpoints in LDS: 2 x 17 planes x 256 B per wave -> four blocks of four waves per CU
 #endif
-#ifndef SFA_FUSED_PERSIST
-#define SFA_FUSED_PERSIST 0  // fused launch: 1 = a wave that has finished its ticket claims the next one itself; 0 = one ticket per wave.
-                             // Measured level (profiles/r02_logs/ab_fused_persistent_waves.log): by the time pass-2 tickets come up the
-                             // fill's tail is already packed by the issue priority, the step is fill work + pass-2 work either way
-
-#endif
 #ifndef SFA_TRACE_WAVES
 #define SFA_TRACE_WAVES 4  // waves per SIMD pass 2 (R <= 16) is register-budgeted for: 128 VGPRs; 3.49 -> 3.28 ms per 100 k reads against 144 VGPRs / 3 waves
 #endif
-#ifndef SFA_XCD_MAP
-#define SFA_XCD_MAP 0  // blockIdx -> task: 0 = as dealt (round-robin over the XCDs), 1 = XCD-contiguous over the grid, 2 = XCD-contiguous per class
-#endif
 constexpr int kStepsPerLoad = SFA_STEPS_PER_LOAD;  // reference levels fetched per load (4 = one 16-byte load)
+constexpr int kSpanBuckets = 32;   // histogram of alignment spans in sixteenths of the query length (FinalizeArgs::span_hist)
 constexpr int kMaxClasses = 6;     // query-length classes; base shapes (R, lanes) = (32,64) (32,32) (32,16) (16,16) (8,16) (4,16)
 
 struct __attribute__((packed, aligned(4))) float4u {
@@ -100,13 +92,12 @@ struct DpArgs {
     // partial results of the fill, index (quad*n_chunks+chunk)*4+slot
     float *p_best;
     int32_t *p_end;
-    int32_t *p_st;
     int32_t *p_job;
     float *p_second;
     // winners per read (written by finalize, read by trace)
     int32_t *w_job;
-    int32_t *w_end;    // two-pass: first column of the winning WINDOW (the trace kernel finds the cell inside it)
-    float *w_score;    // two-pass: the winning score, to recognise that cell
+    int32_t *w_end;    // first column of the winning WINDOW (the trace kernel finds the cell inside it); 32-row shapes: the winning cell's column
+    float *w_score;    // the winning score, to recognise that cell
     ClassDesc cls[kMaxClasses];
     int32_t n_cls;
     int32_t n_chunks;
@@ -144,6 +135,7 @@ struct DpArgs {
     const int32_t *ref_st_offset;
     const uint8_t *bad;
     struct ResultRow *out;
+    unsigned *span_hist;   // fused launch on the 32-row fill: spans of this batch's alignments (see FinalizeArgs::span_hist); else nullptr
     // longest-remaining-first issue priority in the tail of the launch (see IssuePriority): columns per priority step,
     // 0 = off; `started` counts the tasks that have begun (zeroed before the launch)
     int32_t prio_unit;
@@ -177,6 +169,23 @@ __device__ __forceinline__ unsigned simd_position() {
 // (buffer_wbl2) is what this avoids: it writes the whole L2 of the XCD back at the end of every task.
 // Consumer: relaxed poll of the counter, agent-scope acquire (buffer_inv sc1), then plain loads.
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// One write-through store with its offset as an immediate.  The R + 2 planes of a checkpoint record are 256 B apart; written as
+// 34 relaxed atomic stores the compiler materialises 34 64-bit addresses up front and the 32-row fill (128 VGPRs, no slack) spills
+// 1 100 registers into its step loops; with immediate offsets off three base pointers the record costs 6 address registers.
+template <int OFF>
+__device__ __forceinline__ void store_wt(const float *base, const float v) {
+    static_assert(OFF >= 0 && OFF < 4096, "12-bit immediate");
+    asm volatile("global_store_dword %0, %1, off offset:%2 sc1" ::"v"(base), "v"(v), "n"(OFF) : "memory");
+}
+// planes [R costs | dprev | steps elapsed] of a checkpoint record, write-through (read by pass-2 waves of the same launch)
+template <int R, int I = 0, typename CV>
+__device__ __forceinline__ void store_record_wt(float *ckp, const CV &cv, const float dprev, const int e) {
+    if constexpr (I < R + 2) {
+        const float v = I < R ? static_cast<float>(cv[I < R ? I : 0]) : (I == R ? dprev : __int_as_float(e));
+        store_wt<(I % 16) * 256>(ckp + (I / 16) * 16 * 64, v);
+        store_record_wt<R, I + 1>(ckp, cv, dprev, e);
+    }
+}
 
 // A wait that never ends is a hung stream and, on this pool, a lost box.  Every spin of a launch is bounded by wall-clock
 // time (s_memrealtime: 100 MHz): when the limit passes the wave records what it waited for in the launch's error words,
@@ -269,43 +278,39 @@ struct Vec {
 // first strict minimum of every window (src/sigfish.c:892-899), two operations per step of ~100 -- instead of the window alone,
 // so that pass 2 starts a query length in front of that cell rather than in front of its window: a quarter to a third of its
 // steps.  (The 16-row shapes cannot afford two more operations on 49; their pass 2 keeps scanning the window.)
-template <int R, bool TRACK, bool STD>
+template <int R, bool STD>
 struct CellFromFill {
-    static constexpr bool value = !TRACK && !STD && R >= 32;
+    static constexpr bool value = !STD && R >= 32;
 };
 
 // Running top-2 of the reference's candidate list for one read (kept in the registers of the lane that owns
 // the last query row).  Insertion rule of update_aln (src/sigfish.c:577-583): a candidate goes in front of
 // everything that is not strictly better, so on equal scores the LATER candidate ranks higher.
-template <bool TRACK>
 struct Top2 {
     float best, second;
-    int32_t end, st, job;
+    int32_t end, job;
     __device__ __forceinline__ void init() {
         best = INFINITY;
         second = INFINITY;
         end = -1;
-        st = -1;
         job = -1;
     }
-    __device__ __forceinline__ bool offer(float sc, int32_t pos, int32_t start, int32_t j) {
+    __device__ __forceinline__ bool offer(float sc, int32_t pos, int32_t j) {
         const bool top = !(sc > best);
         const bool sec = !(sc > second);
         second = top ? best : (sec ? sc : second);
         best = top ? sc : best;
         end = top ? pos : end;
-        if (TRACK) st = top ? start : st;
         job = top ? j : job;
         return top;
     }
     // the same for the lanes where `on` holds (reads of a wave whose windows end at different columns)
-    __device__ __forceinline__ bool offer_if(bool on, float sc, int32_t pos, int32_t start, int32_t j) {
+    __device__ __forceinline__ bool offer_if(bool on, float sc, int32_t pos, int32_t j) {
         const bool top = on && !(sc > best);
         const bool sec = on && !(sc > second);
         second = top ? best : (sec ? sc : second);
         best = top ? sc : best;
         end = top ? pos : end;
-        if (TRACK) st = top ? start : st;
         job = top ? j : job;
         return top;
     }
@@ -327,15 +332,6 @@ struct MixedQuad {
         g0 = (qmax - myq) / R;
     }
 };
-
-// XCD-contiguous block remap (8 XCDs, blocks dealt round-robin): each XCD gets a contiguous range of logical
-// blocks, hence (tasks being chunk-major inside a class) mostly one reference chunk per XCD L2.  Only compiled in by the
-// A/B modes SFA_XCD_MAP = 1 / 2; the shipped mapping is the identity (see sdtw_fill_kernel).
-__device__ __forceinline__ int xcd_contiguous_block(int b, int nblk) {
-    const int x = b & 7, i = b >> 3;
-    const int q = nblk >> 3, rem = nblk & 7;
-    return x * q + (x < rem ? x : rem) + i;
-}
 
 // Issue priority by remaining work, in the tail of a launch.  The SIMD's arbiter serves the OLDEST ready wave first, so
 // six waves that start together do not advance together: measured (tools/task_times.py, 6 equal tasks per SIMD) they end
@@ -404,8 +400,9 @@ struct IssuePriority {
 //   T0     std_dtw only: t may be 0 in this step (the special case of row 0's first column).  The cost-only fill knows that only
 //          the first block of four steps of a job can hold t = 0 and runs every later block without the test (one scalar
 //          compare + branch and one v_cndmask per step: 3.14 -> 3.09 VALU instructions per cell)
-template <int R, bool TRACK, bool STD, typename TT, bool T0 = true, typename CF, typename CI>
-__device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev, const float (&x)[R], const float yv, const TT t,
+//   x      the lane's R query rows: a register array, or LdsRows (pass 2 of the 32-row shapes inside the fill launch)
+template <int R, bool TRACK, bool STD, typename TT, bool T0 = true, typename CF, typename CI, typename XT>
+__device__ __forceinline__ void dp_step(CF &c, CI &s, float &dprev, int &sdprev, const XT &x, const float yv, const TT t,
                                         const bool lane0, Exchange &xc) {
     // inputs from the lane above (query row g*R-1); lane 0 owns query row 0 and receives the boundary instead:
     // subsequence(): C[0][j] = d + 0 (free start); std_dtw(): C[0][0] = d, then C[0][j] = d + C[0][j-1] (boundary +inf)
@@ -467,8 +464,28 @@ __device__ __forceinline__ void load_query_rows(float (&x)[R], const DpArgs &a, 
     }
 }
 
+// The lane's query rows in LDS instead of registers: plane r of the wave's block, 64 lanes wide.  Pass 2 of the 32-row shapes inside
+// the fill launch runs on that launch's 128-VGPR budget; costs, start columns and query rows (3 x 32 registers) do not fit it, and
+// spilled to scratch they were reloaded in every step (85 scratch loads per four steps).  The rows are read once per cell, so they
+// are the ones to go: one ds_read_b32 with an immediate offset per cell.  volatile: the loads stay where they are (hoisted out of
+// the step loop they would be registers again).
+struct LdsRows {
+    typedef __attribute__((address_space(3))) volatile float lds_vf;
+    float *p;  // this lane's column of the wave's [R][64] block
+    __device__ __forceinline__ float operator[](const int r) const { return *((lds_vf *)(p + r * 64)); }
+    template <int R>
+    __device__ __forceinline__ void load(const DpArgs &a, int read, int qlen, int g, int g0) {
+        const float *q = a.queries + a.q_off[read >= 0 ? read : 0];
+        for (int r = 0; r < R; ++r) {
+            const int i = (g - g0) * R + r;
+            const int src = a.rev_query ? (qlen - 1 - i) : i;
+            *((lds_vf *)(p + r * 64)) = (read >= 0 && i >= 0 && i < qlen) ? q[src] : 0.0f;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------
-// Pass 1 (and, with TRACK, the single-pass variant): fill.  One wave-task = (quad, chunk of jobs).
+// Pass 1: fill (costs only).  One wave-task = (quad, chunk of jobs).
 // ---------------------------------------------------------------------------------------------------------
 // Time origin.  Lane lq (owner of the last query row) meets reference column 0 at step t = lq.  Steps are issued
 // in blocks of four (one 16-byte load of reference levels per block), so the sweep starts at
@@ -556,13 +573,14 @@ struct LdsCkpt {
 
 // One (contig,strand) sweep of a quad.  RQ >= 0: the register holding the last query row is a compile-time
 // constant (hot specialisation); RQ < 0: it is the wave-uniform value rq (indexed v_mov).
-template <int R, bool TRACK, bool STD, int RQ, bool LCK = false, int L = 16, bool WT = false>
+template <int R, bool STD, int RQ, bool LCK = false, int L = 16, bool WT = false>
 __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
-                                          const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<TRACK> &top,
+                                          const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2 &top,
                                           const int job, float *ckp, const int T, IssuePriority &pr, const MixedQuad &mq,
                                           LdsCkpt *lck = nullptr, const bool owner = false) {
+    constexpr bool TRACK = false;  // start columns are pass 2's business (dp_step<.., TRACK = true> in trace_core)
     typename Vec<float, R>::type cv;
-    typename Vec<int, R>::type sv;
+    typename Vec<int, R>::type sv;  // unused (cost-only), kept for dp_step's signature
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         cv[r] = INFINITY;
@@ -606,13 +624,10 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
                     ckp += ck_planes<R>() * 64;
                 }
             }
-        } else if (!TRACK && T) {
+        } else if (T) {
             if (e >= ck_next && ck_next <= ck_last) {
                 if (WT) {  // read by the pass-2 waves of the same launch
-#pragma unroll
-                    for (int r = 0; r < R; ++r) __hip_atomic_store(ckp + r * 64, static_cast<float>(cv[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ckp + R * 64, dprev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ckp + (R + 1) * 64, __int_as_float(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    store_record_wt<R>(ckp, cv, dprev, e);
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; ++r) ckp[r * 64] = cv[r];
@@ -632,7 +647,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     // tests/test_publish_isa.py and the PMC pass) although its code is textually the plain call.
 #define SFA_DP_STEP(YV, U)                                                                                                   \
     do {                                                                                                                     \
-        if constexpr (STD && !TRACK) {                                                                                       \
+        if constexpr (STD) {                                                                                                 \
             if (e >= kStepsPerLoad)                                                                                          \
                 dp_step<R, TRACK, STD, int, false>(cv, sv, dprev, sdprev, x, (YV), t_begin + e + (U), lane0, xc);            \
             else                                                                                                             \
@@ -655,13 +670,12 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
     // steps start wherever the previous window ended (the 16-byte reference loads need no alignment), so the
     // steady-state block carries no window-end test at all. ----
     int jqv = 0;  // last-row column of the next step
-    // Windows.  std_dtw has one candidate per job, the tracking fill keeps one query length per wave: there a window is qlen
-    // columns for every read of the wave.  The cost-only subsequence fill (MIX) carries reads of different lengths (MixedQuad):
-    // every read has windows of its OWN length, so the sweep is cut wherever ANY read's window ends (wave-uniform: the slots'
-    // window ends live in scalar registers), and at such a point the reads whose window ends there offer their candidate and
-    // start a new one.  With equal lengths that is the old loop: one cut per window.
-    constexpr bool MIX = !TRACK && !STD;
-    constexpr bool CELL = CellFromFill<R, TRACK, STD>::value;
+    // Windows.  std_dtw has one candidate per job and keeps one query length per wave.  The subsequence fill (MIX) carries reads
+    // of different lengths (MixedQuad): every read has windows of its OWN length, so the sweep is cut wherever ANY read's window
+    // ends (wave-uniform: the slots' window ends live in scalar registers), and at such a point the reads whose window ends there
+    // offer their candidate and start a new one.  With equal lengths that is one cut per window.
+    constexpr bool MIX = !STD;
+    constexpr bool CELL = CellFromFill<R, STD>::value;
     constexpr int NS = 64 / L;  // reads per wave
     const int my_slot = (threadIdx.x & 63) / L;
     int q_s[NS], ws_s[NS], we_s[NS];  // per slot: query length, first column and end of its current window
@@ -672,35 +686,25 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
         we_s[sl] = min(q_s[sl], rlen);
     }
     float wmin = INFINITY;
-    int wpos = CELL ? 0 : -1, wst = -1;
+    int wpos = CELL ? 0 : -1;
     for (int col = 0; col < rlen;) {
-        if (!TRACK) pr.at_window(col);
+        pr.at_window(col);
         int nxt = we_s[0];
 #pragma unroll
         for (int sl = 1; sl < NS; ++sl) nxt = min(nxt, we_s[sl]);
-        const int wl = STD ? rlen : (MIX ? nxt - col : min(qlen, rlen - col));  // std_dtw has a single candidate: one "window"
+        const int wl = STD ? rlen : nxt - col;  // std_dtw has a single candidate: one "window"
         const int nb = wl >> 2, rm = wl & 3;
-        if (!MIX) {
-            wmin = INFINITY;
-            wpos = CELL ? col : -1;
-            wst = -1;
-        }
-        // Cost-only pass, 16-row shapes: only the window MINIMUM is kept (one v_min per step); which column attains it first
-        // is settled in pass 2 for the single window that wins.  32-row shapes (CELL) also keep the column of the first strict
-        // minimum.  With tracking (single-pass mode) the first strict minimum, its column and its start column are selected
-        // here, as src/sigfish.c:892-899 does.
+        // 16-row shapes: only the window MINIMUM is kept (one v_min per step); which column attains it first is settled in pass 2
+        // for the single window that wins.  32-row shapes (CELL) also keep the column of the first strict minimum
+        // (src/sigfish.c:892-899).
         auto track = [&]() {
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
-            if (!TRACK && !CELL) {
+            if (!CELL) {
                 wmin = fminf(wmin, cl);
             } else {
                 const bool lt = cl < wmin;
                 wmin = lt ? cl : wmin;
                 wpos = lt ? jqv : wpos;
-                if (TRACK) {
-                    const int sl = (RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq]);
-                    wst = lt ? sl : wst;
-                }
                 jqv += 1;
             }
         };
@@ -751,7 +755,7 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
             }
             const bool ending = (endmask >> (threadIdx.x & 63)) & 1;
             // (cost-only, 16-row shapes: the window is identified by its first column)
-            const bool became_best = top.offer_if(ending, wmin, CELL ? wpos : wsl, wst, job);
+            const bool became_best = top.offer_if(ending, wmin, CELL ? wpos : wsl, job);
             if (LCK) {
                 const unsigned long long improved = __ballot(became_best && owner);
                 if (improved) lck->template save<R, L, WT>(improved, wmin, wsl + e_main, a.trace_margin, lq, job, a.lck_shift);
@@ -765,12 +769,9 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
                     we_s[sl] = min(nxt + q_s[sl], rlen);
                 }
             }
-        } else if (!STD) {
-            top.offer(wmin, wpos, wst, job);  // (tracking fill: the first strict minimum of the window, its column and start)
         } else {  // std_dtw: the single candidate C[n-1][m-1]
             const float cl = (RQ >= 0) ? static_cast<float>(cv[RQ >= 0 ? RQ : 0]) : static_cast<float>(cv[rq]);
-            const int sl = TRACK ? ((RQ >= 0) ? static_cast<int>(sv[RQ >= 0 ? RQ : 0]) : static_cast<int>(sv[rq])) : 0;
-            top.offer(cl, rlen - 1, sl, job);
+            top.offer(cl, rlen - 1, job);
         }
         col += wl;
     }
@@ -780,22 +781,22 @@ __device__ __forceinline__ void sweep_job(const DpArgs &a, const float *yp, cons
 
 // Dispatch on the register of the last query row: compile-time constant for the cost-only subsequence fill (worth
 // 5-20 % on the small-batch shapes, whose steps are short).
-template <int R, bool TRACK, bool STD, bool LCK = false, int L = 16, bool WT = false, int I = 0>
+template <int R, bool STD, bool LCK = false, int L = 16, bool WT = false, int I = 0>
 __device__ __forceinline__ void sweep_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
-                                               const float (&x)[R], bool lane0, Exchange &xc, Top2<TRACK> &top, int job, float *ckp, int T,
+                                               const float (&x)[R], bool lane0, Exchange &xc, Top2 &top, int job, float *ckp, int T,
                                                IssuePriority &pr, const MixedQuad &mq, LdsCkpt *lck = nullptr, bool owner = false) {
-    if constexpr (TRACK || STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
-        sweep_job<R, TRACK, STD, -1, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
+    if constexpr (STD || R > 16) {  // R = 32 keeps the indexed read: 32 more loop bodies are not worth the build time
+        sweep_job<R, STD, -1, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
     } else {
         if (rq == I) {
-            sweep_job<R, TRACK, STD, I, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
+            sweep_job<R, STD, I, LCK, L, WT>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
         } else if constexpr (I + 1 < R) {
-            sweep_dispatch<R, TRACK, STD, LCK, L, WT, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
+            sweep_dispatch<R, STD, LCK, L, WT, I + 1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, lck, owner);
         }
     }
 }
 
-template <int R, int L, bool TRACK, bool STD, bool LCK = false, bool FUSED = false>
+template <int R, int L, bool STD, bool LCK = false, bool FUSED = false>
 __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, const int task_local, float *lds_f, int *lds_i,
                                           float *lds_ck = nullptr) {
     const int chunk = task_local / cd.n_quads;  // chunk-major: neighbouring waves stream the same reference
@@ -823,17 +824,17 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
     Exchange xc;
     xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L, mq.g0);
 
-    Top2<TRACK> top;
+    Top2 top;
     top.init();
 
-    const int T = (!TRACK && a.ck_shift) ? (1 << a.ck_shift) : 0;
+    const int T = a.ck_shift ? (1 << a.ck_shift) : 0;
     const int64_t ck_total = T ? a.job_ck_off[a.chunk_begin[a.n_chunks]] : 0;
 
     const int jb = a.chunk_begin[chunk], je = a.chunk_begin[chunk + 1];
     IssuePriority pr;
     {
         int cols = 0;
-        const bool on = !TRACK && a.prio_unit > 0;
+        const bool on = a.prio_unit > 0;
         if (on)
             for (int job = jb; job < je; ++job) cols += a.job_len[job];
         // fused launch: the ticket counter already says how many tasks have begun
@@ -859,7 +860,7 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
         const float *yp = a.ref + a.job_off[job] - g + t_begin;  // this lane's column at step t is t-g
         float *ckp = nullptr;
         if (T) ckp = a.ck + cd.ck_base + (static_cast<int64_t>(quad_local) * ck_total + a.job_ck_off[job]) * (ck_planes<R>() * 64) + lane;
-        sweep_dispatch<R, TRACK, STD, LCK, L, FUSED>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, &lck, g == lq && read >= 0);
+        sweep_dispatch<R, STD, LCK, L, FUSED>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, pr, mq, &lck, g == lq && read >= 0);
     }
 
     if (g == lq && read >= 0) {
@@ -874,7 +875,6 @@ __device__ __forceinline__ void fill_body(const DpArgs &a, const ClassDesc cd, c
             a.p_second[o] = top.second;
             a.p_end[o] = top.end;
             a.p_job[o] = top.job;
-            if (TRACK) a.p_st[o] = top.st;
         }
     }
     if (FUSED) {
@@ -911,7 +911,7 @@ __device__ __forceinline__ int64_t verify_slot(const DpArgs &a, int quad, int jo
 
 template <int R, int RQ>
 __device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, const int rlen, const int qlen, const int lq, const int rq,
-                                              const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2<false> &top,
+                                              const int t_begin, const float (&x)[R], const bool lane0, Exchange &xc, Top2 &top,
                                               const int job, float *ckp, const int T, const int col0, const int col_real, const int col_end,
                                               float *vin, float *vout) {
     typename Vec<float, R>::type cv;
@@ -963,7 +963,7 @@ __device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, 
         if (col == col_real && vin) snapshot(vin);
         const int wl = min(qlen, rlen - col);
         const int nb = wl >> 2, rm = wl & 3;
-        constexpr bool CELL = CellFromFill<R, false, false>::value;
+        constexpr bool CELL = CellFromFill<R, false>::value;
         float wmin = INFINITY;
         int wpos = col, jq = col;  // (CELL) column of the window's first strict minimum / of the next last-row cell
         auto track = [&]() {
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, 
             e += rm;
             ycur = ynext;
         }
-        if (col >= col_real) top.offer(wmin, CELL ? wpos : col, -1, job);
+        if (col >= col_real) top.offer(wmin, CELL ? wpos : col, job);
         col += wl;
     }
     if (vout) snapshot(vout);
@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void sweep_segment(const DpArgs &a, const float *yp, 
 
 template <int R, int I = 0>
 __device__ __forceinline__ void segment_dispatch(const DpArgs &a, const float *yp, int rlen, int qlen, int lq, int rq, int t_begin,
-                                                 const float (&x)[R], bool lane0, Exchange &xc, Top2<false> &top, int job, float *ckp, int T,
+                                                 const float (&x)[R], bool lane0, Exchange &xc, Top2 &top, int job, float *ckp, int T,
                                                  int col0, int col_real, int col_end, float *vin, float *vout) {
     if constexpr (R > 16) {
         sweep_segment<R, -1>(a, yp, rlen, qlen, lq, rq, t_begin, x, lane0, xc, top, job, ckp, T, col0, col_real, col_end, vin, vout);
@@ -1058,7 +1058,7 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
     const int lq = (qlen - 1) / R;
     const int rq = (qlen - 1) - lq * R;
     const int t_begin = sweep_begin(lq);
-    Top2<false> top;
+    Top2 top;
     top.init();
     const int rlen = a.job_len[job];
     const SegRange sr = segment_range(rlen, qlen, a.n_seg, a.warm_windows, seg);
@@ -1096,11 +1096,11 @@ __device__ __forceinline__ void fill_body_seg(const DpArgs &a, const ClassDesc c
 // the fill loops would then read `a.xyz` from there, per lane, instead of from scalar registers -- measured as a scratch
 // load in every block of four steps; passing the 600-byte block by value costs a per-LANE stack copy per call instead,
 // 0.95 GB of scratch writes per 100 000-read launch)
-template <int MAXR, bool STD>
-__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i);
+template <int MAXR, bool STD, bool LCK>
+__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i, float *lds_x);
 
 // LCK: rolling checkpoints in LDS (LdsCkpt) -- two snapshots of 17 planes per wave, 34 KB per block, four blocks per CU.
-// FUSED (with LCK): pass 2 rides in the same launch.  Waves claim TICKETS from a counter instead of deriving their task from
+// FUSED (with LCK, or on the 32-row fill, whose snapshots go to HBM write-through): pass 2 rides in the same launch.  Waves claim TICKETS from a counter instead of deriving their task from
 // blockIdx: tickets below n_tasks are the fill tasks, in the usual order; ticket n_tasks + q is pass 2 of quad q, which waits
 // until every fill task of that quad has signalled completion, merges their partial results (what sdtw_finalize_kernel
 // does between the launches otherwise), recovers the start columns and writes the quad's rows.  Because a ticket is only
@@ -1108,73 +1108,57 @@ __device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa,
 // deadlock whatever order the hardware starts blocks in.  The point: when the fill's last tasks drain, SIMDs go idle one
 // after the other for ~2 ms; the pass-2 tickets are claimed exactly then, so pass 2 (3 ms as its own
 // launch) runs in that slack, at the lowest issue priority, and two launches + the kernel boundaries disappear.
-template <int MAXR, bool TRACK, bool STD, bool SEG = false, bool LCK = false, bool FUSED = false>
-__global__ void __launch_bounds__(256, TRACK ? 1 : (LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES)))) sdtw_fill_kernel(const DpArgs a) {
-    static_assert(!SEG || (!TRACK && !STD), "segments: cost-only subsequence DTW");
-    static_assert(!LCK || (!TRACK && !SEG && MAXR <= 16), "LDS checkpoints: the cost-only fill, R <= 16 (std_dtw: sparse HBM store only)");
-    static_assert(!FUSED || LCK, "the fused launch is built on the LDS-checkpoint fill");
+template <int MAXR, bool STD, bool SEG = false, bool LCK = false, bool FUSED = false>
+__global__ void __launch_bounds__(256, LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_FILL_WAVES : (STD ? 1 : SFA_FILL32_WAVES))) sdtw_fill_kernel(const DpArgs a) {
+    static_assert(!SEG || !STD, "segments: subsequence DTW");
+    static_assert(!LCK || (!SEG && MAXR <= 16), "LDS checkpoints: R <= 16 (std_dtw: sparse HBM store only)");
+    static_assert(!FUSED || LCK || (MAXR == 32 && !SEG && !STD), "pass 2 by ticket: on the LDS-checkpoint fill, or on the 32-row fill (snapshots in HBM)");
     // blockIdx -> task.  Blocks are dealt to the 8 XCDs round-robin, so with the identity every XCD sees every class and
     // every chunk of the job list evenly -- what this kernel wants: the reference arrays (hundreds of KB to a few MB) stay
-    // resident in every XCD's L2 anyway, whereas the classes differ in speed.  Measured (A/B builds, fill ms): identity
-    // 75.9 / contiguous per class 76.2 / contiguous over the grid 77.7 on the headline workload, 269 / 275 / 278 on RNA004
-    // --dtw-std, 2 438 / 2 438 / 2 474 on the 1 Mb reference.  (One contiguous range per XCD over the whole grid hands all
-    // the short, fast classes at the end of the task list to the last XCD, which then idles while the other seven finish.)
-    int lblk = blockIdx.x;
-#if SFA_XCD_MAP == 1
-    lblk = xcd_contiguous_block(blockIdx.x, gridDim.x);
-#elif SFA_XCD_MAP == 2
-    {
-        int cb = 0;
-        while (cb + 1 < a.n_cls && static_cast<int>(blockIdx.x) >= (a.cls[cb + 1].task_base >> 2)) ++cb;
-        const int lo = a.cls[cb].task_base >> 2;
-        const int hi = (cb + 1 < a.n_cls) ? (a.cls[cb + 1].task_base >> 2) : static_cast<int>(gridDim.x);
-        lblk = lo + xcd_contiguous_block(blockIdx.x - lo, hi - lo);
-    }
-#endif
-    int task = __builtin_amdgcn_readfirstlane(lblk * 4 + (threadIdx.x >> 6));
+    // resident in every XCD's L2 anyway, whereas the classes differ in speed.  Measured against XCD-contiguous mappings (LABNOTES.md,
+    // fill ms): identity 75.9 / contiguous per class 76.2 / contiguous over the grid 77.7 on the headline workload, 269 / 275 /
+    // 278 on RNA004 --dtw-std, 2 438 / 2 438 / 2 474 on the 1 Mb reference.  (One contiguous range per XCD over the whole grid hands
+    // all the short, fast classes at the end of the task list to the last XCD, which then idles while the other seven finish.)
+    int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     __shared__ float lds_f[4 * kXchWordsPerWave];
-    __shared__ int lds_i[(TRACK || FUSED) ? 4 * kXchWordsPerWave : 1];
+    __shared__ int lds_i[FUSED ? 4 * kXchWordsPerWave : 1];
     __shared__ float lds_ck[(LCK && !STD) ? 4 * 2 * kLdsCkPlanes * 64 : 1];
-    // FUSED with SFA_FUSED_PERSIST: a wave works through tickets until they run out instead of leaving its slot to a new block
-    for (;;) {
-        if (FUSED) {
-            unsigned t = 0;
-            if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            task = __builtin_amdgcn_readfirstlane(t);
-            if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
-                const int quad = task - a.n_tasks;
-                if (quad >= a.n_quads_total) return;
-                fused_trace_dispatch<MAXR, STD>(a.self, quad, lds_f, lds_i);
-                if (SFA_FUSED_PERSIST) continue;
-                return;
-            }
+    __shared__ float lds_x[(FUSED && MAXR == 32) ? 4 * 32 * 64 : 1];  // query rows of the 32-row shapes' pass 2 (LdsRows): 32 KB per block, four blocks per CU
+    if (FUSED) {  // one ticket per wave (a wave that claimed the next one itself measured level: LABNOTES.md)
+        unsigned t = 0;
+        if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        task = __builtin_amdgcn_readfirstlane(t);
+        if (task >= a.n_tasks) {  // pass 2 of quad (task - n_tasks)
+            const int quad = task - a.n_tasks;
+            if (quad >= a.n_quads_total) return;
+            fused_trace_dispatch<MAXR, STD, LCK>(a.self, quad, lds_f, lds_i, lds_x);
+            return;
         }
-        if (task >= a.n_tasks) return;  // wave-uniform
-        int ci = 0;
-        while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
-        const ClassDesc cd = a.cls[ci];
-        const int tl = task - cd.task_base;
-#define SFA_SHAPE(RR, LL)                                                                    \
-    case (RR) * 256 + (LL):                                                                  \
-        if constexpr (MAXR >= (RR)) {                                                        \
-            if constexpr (SEG)                                                               \
-                fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */   \
-            else                                                                             \
-                fill_body<RR, LL, TRACK, STD, LCK, FUSED>(a, cd, tl, lds_f, lds_i, lds_ck);  \
-        }                                                                                    \
-        break;
-        switch (cd.R * 256 + cd.lanes) {
-            SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
-            SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
-            SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
-            SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
-            SFA_SHAPE(4, 16)
-            default:
-                break;
-        }
-#undef SFA_SHAPE
-        if (!(FUSED && SFA_FUSED_PERSIST)) return;
     }
+    if (task >= a.n_tasks) return;  // wave-uniform
+    int ci = 0;
+    while (ci + 1 < a.n_cls && task >= a.cls[ci + 1].task_base) ++ci;
+    const ClassDesc cd = a.cls[ci];
+    const int tl = task - cd.task_base;
+#define SFA_SHAPE(RR, LL)                                                                \
+    case (RR) * 256 + (LL):                                                              \
+        if constexpr (MAXR >= (RR)) {                                                    \
+            if constexpr (SEG)                                                           \
+                fill_body_seg<RR, LL>(a, cd, tl, lds_f, lds_i); /* (quad, job, segment) */ \
+            else                                                                         \
+                fill_body<RR, LL, STD, LCK, FUSED>(a, cd, tl, lds_f, lds_i, lds_ck);     \
+        }                                                                                \
+        break;
+    switch (cd.R * 256 + cd.lanes) {
+        SFA_SHAPE(32, 64) SFA_SHAPE(32, 32) SFA_SHAPE(32, 16)
+        SFA_SHAPE(16, 64) SFA_SHAPE(16, 32) SFA_SHAPE(16, 16)
+        SFA_SHAPE(8, 64) SFA_SHAPE(8, 32) SFA_SHAPE(8, 16)
+        SFA_SHAPE(4, 64) SFA_SHAPE(4, 32)
+        SFA_SHAPE(4, 16)
+        default:
+            break;
+    }
+#undef SFA_SHAPE
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1191,9 +1175,9 @@ struct Winner {
     int chunk;   // LCK: the task whose record holds the snapshot
 };
 
-template <int R, int L, bool STD, bool LCK = false>
+template <int R, int L, bool STD, bool LCK = false, bool XLDS = false>
 __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, const int quad_local, const Winner w, float *lds_f, int *lds_i,
-                                           int &res_st, int &res_end);
+                                           int &res_st, int &res_end, float *lds_x = nullptr);
 
 template <int R, int L, bool STD, bool LCK = false>
 __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, const int quad_local, int32_t *out_st, float *lds_f,
@@ -1216,9 +1200,9 @@ __device__ __forceinline__ void trace_body(const DpArgs &a, const ClassDesc cd, 
     }
 }
 
-template <int R, int L, bool STD, bool LCK>
+template <int R, int L, bool STD, bool LCK, bool XLDS>
 __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, const int quad_local, const Winner w, float *lds_f, int *lds_i,
-                                           int &res_st, int &res_end) {
+                                           int &res_st, int &res_end, float *lds_x) {
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
     const int g = lane & (L - 1);
@@ -1232,13 +1216,18 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     mq.template init<R>(a, read, qlen);
     const bool lane0 = (g == mq.g0);
 
-    float x[R];
-    load_query_rows<R>(x, a, read, mq.myq, g, mq.g0);
+    float x[XLDS ? 1 : R];
+    LdsRows xl;  // XLDS: the rows live in LDS (lds_x: [4 waves][R][64])
+    xl.p = XLDS ? lds_x + (threadIdx.x >> 6) * (R * 64) + lane : nullptr;
+    if constexpr (XLDS)
+        xl.template load<R>(a, read, mq.myq, g, mq.g0);
+    else
+        load_query_rows<R>(x, a, read, mq.myq, g, mq.g0);
     Exchange xc;
     xc.init(lds_f, lds_i, threadIdx.x >> 6, slot, g, L, mq.g0);
 
     int job = (read >= 0) ? w.job : -1;
-    constexpr bool CELL = CellFromFill<R, false, STD>::value && !LCK;
+    constexpr bool CELL = CellFromFill<R, STD>::value && !LCK;
     const int ws = (read >= 0) ? w.ws : 0;  // first column of the winning window; CELL: the column of the winning cell itself
     const float best = (read >= 0) ? w.best : 0.0f;
     bool done = !(read >= 0 && job >= 0 && ws >= 0);
@@ -1336,7 +1325,10 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
 #pragma unroll
             for (int u = 0; u < kStepsPerLoad; ++u) {
                 const int t = tb + tau0 + u;
-                dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t - mq.g0, lane0, xc);  // (the column of the lane holding row 0)
+                if constexpr (XLDS)
+                    dp_step<R, true, STD, int>(c, s, dprev, sdprev, xl, yv.v[u], t - mq.g0, lane0, xc);
+                else
+                    dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t - mq.g0, lane0, xc);  // (the column of the lane holding row 0)
                 const float cl = c[rq];
                 const int sl = s[rq];
                 const bool hit = (cap_end < 0) && !bad_rec && (t >= t_first) && (t <= t_last) && (cl == best);
@@ -1375,31 +1367,28 @@ struct FinalizeArgs {
     const int32_t *slot_of_read;  // [n_reads] quad*4+slot, or -1 for skipped reads
     const float *p_best;
     const int32_t *p_end;
-    const int32_t *p_st;  // single-pass variant only
     const int32_t *p_job;
     const float *p_second;
     const int32_t *job_contig;  // [n_jobs]
     const int8_t *job_strand;   // [n_jobs] '+' / '-'
     const int32_t *ref_len;     // [num_ref]
     const int32_t *ref_st_offset;
-    int32_t *w_job;  // two-pass: winners for the trace kernel
+    int32_t *w_job;  // winners for the trace kernel
     int32_t *w_end;
     float *w_score;
     int32_t *w_chunk;  // chunk (task) the winner came from: where the LCK fill left its snapshot
-    const int32_t *t_st;  // two-pass, second finalize: start columns [n_reads] then end columns [n_reads] from the trace kernel
+    const int32_t *t_st;  // second finalize: start columns [n_reads] then end columns [n_reads] from the trace kernel
     ResultRow *out;       // [n_reads]
     const uint8_t *bad;   // [n_reads] 1: a query value is NaN or +-inf (sdtw_screen_kernel) -> the read is skipped
     const int64_t *q_off;  // [n_reads+1]; with max_query: a longer read belongs to the row-strip path (sdtw_strips.hpp), which
     int32_t max_query;     // writes its row from another stream -- no row is written for it here (0: every row is written)
     int32_t n_reads, n_chunks;
-    int32_t mode;  // 0: single pass (p_st valid) -> full rows; 1: after fill -> winners + scores; 2: after trace -> positions;
+    int32_t mode;  // 1: after fill -> winners + scores; 2: after trace -> positions;
                    // 3: fused launch -> rows of the reads that are in no quad (skipped), the rest is written by its pass-2 waves
     // mode 2: how many reference columns the alignments of this batch span, in sixteenths of their query length (32 buckets, the
     // last one open): what the next batch's pass 2 takes as its head start instead of a whole query length (nullptr: not kept)
     unsigned *span_hist;
 };
-constexpr int kSpanBuckets = 32;
-
 template <int MAXR, bool STD, bool LCK = false>
 __global__ void __launch_bounds__(256, MAXR <= 16 ? SFA_TRACE_WAVES : 1) sdtw_trace_kernel(const DpArgs a, int32_t *out_st) {
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1439,8 +1428,8 @@ __device__ __forceinline__ uint8_t mapq_from_scores(float score, float score2) {
     return static_cast<uint8_t>(q);
 }
 
-template <int R, int L, bool STD>
-__device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDesc cd, const int quad_local, float *lds_f, int *lds_i) {
+template <int R, int L, bool STD, bool LCK>
+__device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDesc cd, const int quad_local, float *lds_f, int *lds_i, float *lds_x) {
     const int quad = cd.quad_base + quad_local;
     const int lane = threadIdx.x & 63;
     const int g = lane & (L - 1);
@@ -1510,19 +1499,27 @@ __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDes
     w.best = __shfl(w.best, src);
     w.chunk = __shfl(w.chunk, src);
     int res_st, res_end;
-    trace_core<R, L, STD, true>(a, cd, quad_local, w, lds_f, lds_i, res_st, res_end);
+    trace_core<R, L, STD, LCK, (R == 32)>(a, cd, quad_local, w, lds_f, lds_i, res_st, res_end, lds_x);
     if (owner) {
         if (r.rid >= 0) {  // src/sigfish.c:971-975
             const int rl = a.ref_len[r.rid], off = a.ref_st_offset[r.rid];
             r.pos_st = ((r.strand == '+') ? res_st : rl - res_end) + off;
             r.pos_end = ((r.strand == '+') ? res_end : rl - res_st) + off;
+            // how many reference columns this alignment spans, in sixteenths of its query length (sdtw_finalize_kernel, mode 2)
+            if (a.span_hist && res_st >= 0 && res_end >= res_st) {
+                const int64_t ql = a.q_off[read + 1] - a.q_off[read];
+                if (ql > 0) {
+                    const int64_t b = (static_cast<int64_t>(res_end - res_st + 1) * 16) / ql;
+                    atomicAdd(a.span_hist + (b < kSpanBuckets - 1 ? static_cast<int>(b) : kSpanBuckets - 1), 1u);
+                }
+            }
         }
         a.out[read] = r;
     }
 }
 
-template <int MAXR, bool STD>
-__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i) {
+template <int MAXR, bool STD, bool LCK>
+__device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa, const int quad, float *lds_f, int *lds_i, float *lds_x) {
     const DpArgs &a = *pa;
     int ci = 0;
     while (ci + 1 < a.n_cls && quad >= a.cls[ci + 1].quad_base) ++ci;
@@ -1530,9 +1527,10 @@ __device__ __attribute__((noinline)) void fused_trace_dispatch(const DpArgs *pa,
     const int ql = quad - cd.quad_base;
 #define SFA_TSHAPE(RR, LL)                                                               \
     case (RR) * 256 + (LL):                                                              \
-        if constexpr (MAXR >= (RR)) fused_trace_task<RR, LL, STD>(a, cd, ql, lds_f, lds_i); \
+        if constexpr (MAXR >= (RR)) fused_trace_task<RR, LL, STD, LCK>(a, cd, ql, lds_f, lds_i, lds_x); \
         break;
     switch (cd.R * 256 + cd.lanes) {
+        SFA_TSHAPE(32, 64) SFA_TSHAPE(32, 32) SFA_TSHAPE(32, 16)
         SFA_TSHAPE(16, 64) SFA_TSHAPE(16, 32) SFA_TSHAPE(16, 16)
         SFA_TSHAPE(8, 64) SFA_TSHAPE(8, 32) SFA_TSHAPE(8, 16)
         SFA_TSHAPE(4, 64) SFA_TSHAPE(4, 32) SFA_TSHAPE(4, 16)
@@ -1642,7 +1640,7 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
     if (sl >= 0 && !a.bad[i]) {
         const int64_t quad = sl >> 2, slot = sl & 3;
         float best = INFINITY, second = INFINITY;
-        int end = -1, st = -1, job = -1;
+        int end = -1, job = -1;
         for (int ch = 0; ch < a.n_chunks; ++ch) {  // chunks in processing order: a later chunk wins ties
             const int64_t o = (quad * a.n_chunks + ch) * 4 + slot;
             const float b = a.p_best[o], s2 = a.p_second[o];
@@ -1655,7 +1653,6 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
                 end = a.p_end[o];
                 job = a.p_job[o];
                 wchunk = ch;
-                if (a.mode == 0) st = a.p_st[o];
             }
         }
         r.valid = 1;
@@ -1667,12 +1664,6 @@ __global__ void __launch_bounds__(256) sdtw_finalize_kernel(const FinalizeArgs a
             r.rid = rid;
             r.strand = d;
             r.mapq = mapq_from_scores(best, second);
-            if (a.mode == 0) {
-                const int rl = a.ref_len[rid];
-                const int off = a.ref_st_offset[rid];
-                r.pos_st = ((d == '+') ? st : rl - end) + off;
-                r.pos_end = ((d == '+') ? end : rl - st) + off;
-            }
             wjob = job;
             wend = end;
         }

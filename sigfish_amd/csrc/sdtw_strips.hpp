@@ -11,20 +11,19 @@
 //     later, its diagonal input) from that row instead of the constant boundary;
 //   * the final strip holds the last query row: the window scan of src/sigfish.c:891-901 / 938-948 and the top-2 of
 //     update_aln (src/sigfish.c:575-626) run there.
-// TWO PASSES, as in the wave kernels.  Pass 1 (sdtw_strip_kernel<STD, false>, one wave per (read, contig, strand)) evaluates
-// costs only -- v_sub, v_min3, v_add per cell -- keeps every window's minimum and drops a checkpoint of every strip's
-// anti-diagonal state (32 costs + the diagonal input per lane) every T steps; the strip finalize merges the per-job top-2
-// and names the winning (job, window, score).  Pass 2 (sdtw_strip_kernel<STD, true>, one wave per read) sweeps the WINNING
-// job again, all strips from the same checkpoint a query length (+64) before the winning window to the end of that window,
-// with the start column carried forward by the traceback rule of path() (diagonal, then left, then up;
-// src/cdtw.c:134-146), the boundary rows now holding (cost, start column); the first cell of the window whose cost equals
-// the winning score bit for bit is the reference's first strict minimum, and the start carried into it is where
-// subsequence_path() ends.  Restored cells carry start -1; if -1 reaches the winning cell the path began before the
-// checkpoint and the read backs off 1, 2, 4 ... checkpoints, ultimately to column 0.  Costs are restored bit-exactly and
-// both passes evaluate the same pure fp32 function of three neighbours per cell, so costs agree bit for bit with each
-// other and with the reference.
-// HBM traffic: 4 (pass 1) or 8 (pass 2) bytes per column and strip boundary + 8.4 KB per checkpoint and strip, against
-// 2048 x 3..7 lane-operations per column.
+// TWO PASSES, as in the wave kernels.  Pass 1 (sdtw_strip_pipe_kernel, one wave per (read, contig, strand, STRIP), strip s + 1
+// following strip s through HBM a block of columns behind) evaluates costs only -- v_sub, v_min3, v_add per cell -- keeps every
+// window's first strict minimum and its column, and drops a checkpoint of every strip's anti-diagonal state (up to 32 costs + the
+// diagonal input per lane) every T steps; the strip finalize merges the per-job top-2 and names the winning (job, cell, score).
+// Pass 2 (sdtw_strip_chain_kernel, one wave per read) traces the WINNING job strip by strip from the last one upwards, each
+// strip from a checkpoint in front of its target cell, with the column through which the path enters the strip carried forward
+// by the traceback rule of path() (diagonal, then left, then up; src/cdtw.c:134-146); the cell a strip has to reach is known
+// by column and cost, compared bit for bit.  Restored cells carry -1; if -1 reaches the target cell the path entered before the
+// checkpoint and the strip backs off 1, 2, 4 ... checkpoints, ultimately to column 0.  Costs are restored bit-exactly and both
+// passes evaluate the same pure fp32 function of three neighbours per cell, so costs agree bit for bit with each other and with
+// the reference.
+// HBM traffic: 4 bytes per column and strip boundary + 8.4 KB per checkpoint and strip, against 2048 x 3..7 lane-operations per
+// column.
 #pragma once
 
 #include "sdtw_kernels.hpp"
@@ -41,10 +40,10 @@ constexpr int kCkDprev = kStripR * 64;      // ... and the plane of the diagonal
 // sweep of a strip costs its R, whatever the number of lanes that hold rows, so a quarter of the time goes with the quarter of
 // padding.  (At least 80 % of the rows of the strips of any query are query rows.)  R is a function of the query length alone:
 // both passes, the boundary rows and the checkpoints of a read use the same one.
-__host__ __device__ inline int strip_rows_per_lane(const int qlen, const int balanced) {
+__host__ __device__ inline int strip_rows_per_lane(const int qlen) {
     const int n_strips = (qlen + kStripRows - 1) / kStripRows;
     const int per_lane = (qlen + 64 * n_strips - 1) / (64 * n_strips);
-    const int R = !balanced ? kStripR : (per_lane <= 20 ? 20 : (per_lane <= 24 ? 24 : (per_lane <= 28 ? 28 : 32)));
+    const int R = per_lane <= 20 ? 20 : (per_lane <= 24 ? 24 : (per_lane <= 28 ? 28 : 32));
     return 64 * R * (n_strips - 1) < qlen ? R : kStripR;  // (always: the last strip holds at least one row)
 }
 constexpr int kBndPad = 256;                // words behind every boundary row (block over-run of the sweep + prefetch)
@@ -57,9 +56,7 @@ struct StripArgs {
     const int64_t *job_off;   // [n_jobs]
     const int32_t *job_len;   // [n_jobs]
     const int64_t *bnd_off;   // [n_jobs+1] word offset of job j's boundary row inside one buffer (multiples of 4)
-    float *bnd_cost;          // [n_long][2 buffers][bnd_off[n_jobs]] last-row costs of the previous / current strip
-    int32_t *bnd_start;       // [n_long][2 buffers][bnd_row_max] carried start columns (pass 2: one job per read)
-    int64_t bnd_row_max;      // words of the longest boundary row
+    float *bnd_cost;          // [n_long][max_strips - 1 rows][bnd_off[n_jobs]] last row of every strip but the final one (pass 1 writes, pass 2 reads)
     float *p_best, *p_second; // pass 1: partial top-2 per (long read, job); p_end = column of the best window's first strict minimum
     int32_t *p_end;
     const int32_t *w_job;     // pass 2: winner per long read (from the strip finalize): job, column of the winning cell, score
@@ -72,13 +69,11 @@ struct StripArgs {
     int32_t max_strips;       // strips of the longest query of the launch
     int32_t trace_margin;     // pass 2 resumes at least this many columns before the winning window; < 0: query length + 64
     int32_t n_long, n_jobs, rev_query;
-    // pipelined pass 1 (sdtw_strip_pipe_kernel): one wave per (read, job, STRIP); strip s + 1 follows strip s through HBM
-    int64_t bnd_stride;         // floats between two reads' boundary buffers (pipelined pass 1: max_strips - 1 rows, else 2)
+    // pass 1 (sdtw_strip_pipe_kernel): one wave per (read, job, STRIP); strip s + 1 follows strip s through HBM
+    int64_t bnd_stride;         // floats between two reads' boundary buffers (max_strips - 1 rows)
     const int32_t *strip_off;   // [n_long+1] prefix sum of the reads' strip counts
     int32_t *progress;          // [n_long][n_jobs][max_strips] columns of the strip's last row that are complete and visible
     unsigned *ticket;           // task counter (zeroed before the launch)
-    int32_t balanced;           // 1: rows per lane by query length (strip_rows_per_lane), 0: always 32
-    int32_t keep_rows;          // classic pass 1: 1 = strip s writes boundary row s (bnd_stride rows per read) instead of two rows in turn
     // bounded waits (sdtw_kernels.hpp, bounded_wait_ge): error words, limit in 100 MHz ticks; debug_drop_strip >= 0: strip 0 of
     // that (long read of the group, job 0) publishes no progress (for the test of the bound)
     unsigned *err;
@@ -142,45 +137,34 @@ __device__ __forceinline__ void strip_step(typename Vec<float, R>::type &c, type
     }
 }
 
-// Four columns of a boundary row.  `through`: the row is handed to another wave of the same launch (pipelined pass 1), maybe
-// on another XCD with its own L2: the store writes through to memory (sc1), so that the producer only has to wait for its own
-// stores (publish_fence: an explicit s_waitcnt vmcnt(0)) instead of writing back the whole L2 (a release fence at agent scope is buffer_wbl2 -- with 17 GB of
+// Four columns of a boundary row.  The row is handed to another wave of the same launch, maybe on another XCD with its own L2:
+// the store writes through to memory (sc1), so that the producer only has to wait for its own stores (publish_fence: an explicit
+// s_waitcnt vmcnt(0)) instead of writing back the whole L2 (a release fence at agent scope is buffer_wbl2 -- with 17 GB of
 // checkpoints passing through the same L2, once per kPipeBlock columns and wave).
-#ifndef SFA_STRIP_WT
-#define SFA_STRIP_WT 1
-#endif
-__device__ __forceinline__ void store_row4(float *p, const typename Vec<float, 4>::type v, const bool through) {
-    if (SFA_STRIP_WT && through)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else
-        *reinterpret_cast<typename Vec<float, 4>::type *>(p) = v;
+__device__ __forceinline__ void store_row4(float *p, const typename Vec<float, 4>::type v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void publish_fence() {
-    if (SFA_STRIP_WT)
-        drain_stores();  // explicit s_waitcnt vmcnt(0): this wave's write-through stores have completed (sdtw_kernels.hpp)
-    else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        drain_stores();  // (the compiler may drop the fence's own wait, see drain_stores())
-    }
-}
+__device__ __forceinline__ void publish_fence() { drain_stores(); }  // this wave's write-through stores have completed (sdtw_kernels.hpp)
 
 // What the final strip reports.  Pass 1: the running top-2 over windows (by window).  Pass 2: the winning cell.
 struct StripResult {
-    Top2<false> top;   // pass 1
+    Top2 top;          // pass 1
     int cap_end, cap_st;  // pass 2
 };
 
 // One strip over columns [0, ncols) of one (contig,strand).  LAST: the strip holds the last query row (lane lq,
-// register rq).  Pass 2 (TRACK): [ws, ncols) is the winning window and `best` its minimum.
-template <bool STD, bool FIRST, bool TRACK, bool CHAIN, bool LAST, int R, bool PIPE = false>
+// register rq) -- in pass 2 (TRACK) always: the row of the cell to reach.  Pass 2: column ws is the cell to reach, `best` its cost.
+template <bool STD, bool FIRST, bool TRACK, bool LAST, int R>
 __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen,
                                             const float (&x)[R], const int lq, const int rq, const int lane, Exchange &xc,
-                                            const float *bin_c, const int32_t *bin_s, float *bout_c, int32_t *bout_s, StripResult &res,
+                                            const float *bin_c, float *bout_c, StripResult &res,
                                             const int job, const int ws, const float best, const int t_begin, float *ckp,
                                             const int ck_shift, const int nck, const int32_t *prog_in = nullptr, int32_t *prog_out = nullptr,
                                             unsigned *err = nullptr, const long long spin_limit = 0) {
-    // PIPE (pipelined pass 1), prog_in / prog_out: how far the strip above has got with the row this sweep reads / where to say
-    // how far this sweep has got with the row it writes.  Both wave-uniform.  !PIPE: the rows are complete / nobody is waiting.
+    static_assert(!TRACK || LAST, "pass 2 sweeps a strip up to a cell of its last row");
+    constexpr bool PIPE = !TRACK;  // pass 1 is pipelined: strips of one (read, job) follow each other through HBM
+    // PIPE, prog_in / prog_out: how far the strip above has got with the row this sweep reads / where to say
+    // how far this sweep has got with the row it writes.  Both wave-uniform.  Pass 2: the rows are complete / nobody is waiting.
     // ckp: this strip's checkpoint records (+ lane).  Pass 1 stores record k - 1 before step k*T; pass 2 resumes from the
     // record of step t_begin (t_begin = 0: from the initial state).
     typename Vec<float, R>::type c;
@@ -195,7 +179,7 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             s[r] = -1;
         }
         dprev = rec[kCkDprev];
-        sdprev = (CHAIN && !FIRST && lane == 0) ? t_begin - 1 : -1;  // lane 0's diagonal input is the row above, column t_begin - 1
+        sdprev = (!FIRST && lane == 0) ? t_begin - 1 : -1;  // lane 0's diagonal input is the row above, column t_begin - 1
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -245,11 +229,7 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
     // used (64 steps: a boundary row another wave has just written through comes from HBM, not from this XCD's L2), and
     // every step picks its column with v_readlane.
     float bcur = 0.0f, bnxt = 0.0f;
-    int scur = 0, snxt = 0;
-    if (!FIRST) {
-        bnxt = bin_c[t_begin + lane];
-        if (TRACK && !CHAIN) snxt = bin_s[t_begin + lane];
-    }
+    if (!FIRST) bnxt = bin_c[t_begin + lane];
     for (int t0 = t_begin; t0 < n_steps; t0 += 4) {
         const int cpos = (t0 - t_begin) & 63;  // wave-uniform: position of step t0 inside the 64-column chunk
         // everything that is not a step happens at a chunk start or (checkpoint intervals below 64) at a multiple of T: ONE test
@@ -278,10 +258,6 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             // a large finite pattern so that tools inspecting the buffers see no NaNs; correctness does not rest on it.)
             bcur = bnxt;
             bnxt = bin_c[t0 + 64 + lane];
-            if (TRACK && !CHAIN) {
-                scur = snxt;
-                snxt = bin_s[t0 + 64 + lane];
-            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -290,23 +266,17 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
             int bsup = 0;
             if (!FIRST) {  // the row above query row 0 of this strip: column t of the previous strip's last row
                 bup = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bcur), cpos + u));
-                // CHAIN: what is carried is the COLUMN of the row above through which the path enters this strip
-                if (TRACK) bsup = CHAIN ? t : __builtin_amdgcn_readlane(scur, cpos + u);
+                // what is carried is the COLUMN of the row above through which the path enters this strip
+                if (TRACK) bsup = t;
             }
             strip_step<STD, FIRST, TRACK, R>(c, s, dprev, sdprev, x, ycur.v[u], t, lane0, xc, bup, bsup);
             // (everything below is branch-free but for the end of a window: a taken branch per step costs this loop a fifth of its
             // time -- the wave kernels' sweep has none either)
-            if (!LAST && !TRACK) {
+            if (!LAST) {
                 // lane 63 is at column t - 63 of the strip's last row; t0 is a multiple of 4, so the column is u + 1 (mod 4):
                 // four columns are collected and stored as one aligned 16-byte word when the fourth arrives
                 ob[(u + 1) & 3] = c[R - 1];
-                if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob, PIPE);
-            } else if (!LAST) {
-                const int col = t - 63;
-                if (lane == 63 && col >= 0 && col < ncols) {
-                    bout_c[col] = c[R - 1];
-                    bout_s[col] = s[R - 1];
-                }
+                if (u == 2 && lane == 63 && t0 >= 64) store_row4(bout_c + (t0 - 64), ob);
             } else {
                 const int col = t - lq;                        // wave-uniform
                 const bool inside = col >= 0 && col < ncols;   // wave-uniform
@@ -321,13 +291,13 @@ __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, con
                     wmin = lt ? cv : wmin;
                     wpos = lt ? col : wpos;
                     if (__builtin_expect(col + 1 == wend, 0)) {  // (wend <= ncols: never outside)
-                        res.top.offer(wmin, wpos, -1, job);
+                        res.top.offer(wmin, wpos, job);
                         wmin = INFINITY;
                         wpos = -1;
                         wend = min(wend + qlen, rlen);
                     }
                 } else if (__builtin_expect(col == rlen - 1, 0)) {
-                    res.top.offer(cl, col, -1, job);
+                    res.top.offer(cl, col, job);
                 }
             }
         }
@@ -365,134 +335,20 @@ __device__ __forceinline__ void strip_rows(const StripArgs &a, const StripRead &
 }
 // the kernels pick the body for the read's rows per lane (wave-uniform)
 #define SFA_STRIP_DISPATCH(BODY, qlen, ...)                    \
-    switch (strip_rows_per_lane(qlen, a.balanced)) {          \
+    switch (strip_rows_per_lane(qlen)) {                      \
         case 20: BODY<STD, 20>(__VA_ARGS__); break;           \
         case 24: BODY<STD, 24>(__VA_ARGS__); break;           \
         case 28: BODY<STD, 28>(__VA_ARGS__); break;           \
         default: BODY<STD, 32>(__VA_ARGS__); break;           \
     }
 
-// Pass 1 (TRACK = false): wave-task = (long read, job).  Pass 2 (TRACK = true): wave-task = long read, its winning job.
-// 4 waves per block.
-template <bool STD, bool TRACK, int R>
-__device__ __forceinline__ void strip_task(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
-    const int qlen = rd.qlen, n_strips = rd.n_strips;
-    const int rlen = a.job_len[job];
-    const float *yp = a.ref + a.job_off[job] - lane;  // this lane's column at step t is t - lane
-    const int64_t per = a.bnd_off[a.n_jobs];
-    float *bc = a.bnd_cost + static_cast<int64_t>(li) * a.bnd_stride + a.bnd_off[job];
-    int32_t *bs = TRACK ? a.bnd_start + static_cast<int64_t>(li) * 2 * a.bnd_row_max : nullptr;
-
-    int ws = 0, ncols = rlen;
-    float best = 0.0f;
-    const int nck = (rlen - 1) >> a.ck_shift;  // checkpoints per strip of this job
-    const int T = 1 << a.ck_shift;
-    int k = 0, back = 1;
-    if (TRACK) {
-        ws = a.w_ws[li];
-        best = a.w_score[li];
-        ncols = STD ? rlen : min(rlen, ws + 1);  // columns up to the winning cell (pass 1 names it: p_end is its column)
-        // every cell of a path that starts at or behind column k*T is evaluated after step k*T in every strip; a path of
-        // qlen events rarely spans more than qlen columns -- and when it does, the read backs off
-        const int from = ws - (a.trace_margin >= 0 ? a.trace_margin : qlen + 64);
-        k = from > 0 ? min(from >> a.ck_shift, nck) : 0;
-    }
-    float *ck_job = a.ck + (static_cast<int64_t>(li) * a.ck_off[a.n_jobs] + a.ck_off[job]) * kCkRec + lane;
-    StripResult res;
-    res.top.init();
-    int lq = 0;
-    for (int attempt = 0; attempt < 40; ++attempt) {  // pass 1: once; pass 2: until the start is known (k reaches 0 after <= 32 halvings)
-        res.cap_end = -1;
-        res.cap_st = -1;
-        for (int sidx = 0; sidx < n_strips; ++sidx) {
-            const int rows = min(64 * R, qlen - sidx * 64 * R);
-            const bool last = sidx == n_strips - 1;
-            lq = (rows - 1) / R;
-            const int rq = (rows - 1) - lq * R;
-            float x[R];
-            strip_rows<R>(a, rd, sidx, lane, x);
-            // two rows in turn, or (pass 1 with the chained pass 2 behind it) one row per strip boundary, kept
-            float *bout_c = bc + ((!TRACK && a.keep_rows) ? sidx : (sidx & 1)) * per;
-            const float *bin_c = bc + ((!TRACK && a.keep_rows) ? sidx - 1 : ((sidx & 1) ^ 1)) * per;
-            int32_t *bout_s = TRACK ? bs + (sidx & 1) * a.bnd_row_max : nullptr;
-            const int32_t *bin_s = TRACK ? bs + ((sidx & 1) ^ 1) * a.bnd_row_max : nullptr;
-            float *ckp = ck_job + static_cast<int64_t>(sidx) * nck * kCkRec;
-            // (a strip is long enough for three copies of the loop to pay: first / in between / last)
-            if (sidx == 0)
-                strip_sweep<STD, true, TRACK, false, false, R>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
-                                                               best, k * T, ckp, a.ck_shift, nck);
-            else if (!last)
-                strip_sweep<STD, false, TRACK, false, false, R>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
-                                                                best, k * T, ckp, a.ck_shift, nck);
-            else
-                strip_sweep<STD, false, TRACK, false, true, R>(yp, rlen, ncols, qlen, x, lq, rq, lane, xc, bin_c, bin_s, bout_c, bout_s, res, job, ws,
-                                                               best, k * T, ckp, a.ck_shift, nck);
-            // the boundary row was stored by lane 63 and is loaded by every lane of the same wave in the next strip: complete
-            // the stores and drop the lines the vector cache may still hold from two strips ago
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        if (!TRACK) break;
-        const int st = __builtin_amdgcn_readlane(res.cap_st, lq);  // lq: wave-uniform
-        if (st >= 0 || k == 0) break;
-        k = max(0, k - back);  // the path starts before this checkpoint
-        back <<= 1;
-    }
-    if (lane == lq) {
-        if (TRACK) {
-            a.t_st[li] = res.cap_st;
-            a.t_end[li] = res.cap_end;
-        } else {
-            const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
-            a.p_best[o] = res.top.best;
-            a.p_second[o] = res.top.second;
-            a.p_end[o] = res.top.end;
-        }
-    }
-}
-template <bool STD, int R>
-__device__ __forceinline__ void strip_task_fill(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
-    strip_task<STD, false, R>(a, rd, li, job, lane, xc);
-}
-template <bool STD, int R>
-__device__ __forceinline__ void strip_task_trace(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
-    strip_task<STD, true, R>(a, rd, li, job, lane, xc);
-}
-
-template <bool STD, bool TRACK>
-__global__ void __launch_bounds__(256, TRACK ? 1 : 2) sdtw_strip_kernel(const StripArgs a) {
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (task >= (TRACK ? a.n_long : a.n_long * a.n_jobs)) return;  // wave-uniform
-    int job, li;
-    if (TRACK) {
-        li = task;
-        job = a.w_job[li];
-        if (job < 0) return;  // nothing aligned (no candidate at all)
-    } else {
-        job = task / a.n_long;  // job-major: neighbouring waves stream the same reference
-        li = task - job * a.n_long;
-    }
-    const int lane = threadIdx.x & 63;
-    __shared__ float lds_f[4 * kXchWordsPerWave];
-    __shared__ int lds_i[TRACK ? 4 * kXchWordsPerWave : 1];
-    Exchange xc;
-    xc.init(lds_f, lds_i, threadIdx.x >> 6, 0, lane, 64);
-    const StripRead rd = strip_read(a, li);
-    if (TRACK) {
-        SFA_STRIP_DISPATCH(strip_task_trace, rd.qlen, a, rd, li, job, lane, xc)
-    } else {
-        SFA_STRIP_DISPATCH(strip_task_fill, rd.qlen, a, rd, li, job, lane, xc)
-    }
-}
-
-// Pass 1, pipelined: wave-task = (job, long read, STRIP).  The classic pass 1 above gives one wave all the strips of a (read,
-// job), one after the other: few, long tasks -- 6 250 of them for 3 125 reads of 8 000 events, two-and-a-bit rounds of the
-// resident waves, each four sweeps long (0.69 x 10^13 cells/s against 1.9 x 10^13 for the wave kernels).  Here every strip is
-// its own wave, and strip s + 1 FOLLOWS strip s over the same columns, a block of kPipeBlock columns behind, reading the
-// boundary row strip s writes (one row per strip instead of two rows in turn).  Waves claim tickets in the order job, read,
-// strip: a strip's predecessor always holds a lower ticket, i.e. is running or done whenever the strip waits for it -- no
-// deadlock whatever order the hardware starts blocks in.  Everything else (checkpoints per strip, window scan in the final
-// strip, partial top-2 per (read, job)) is the classic pass 1's.
+// Pass 1: wave-task = (job, long read, STRIP).  One wave walking all the strips of a (read, job) one after the other gives few,
+// long tasks (6 250 for 3 125 reads of 8 000 events, each four sweeps long: 0.69 x 10^13 cells/s against 1.9 x 10^13 for the
+// wave kernels).  Here every strip is its own wave, and strip s + 1 FOLLOWS strip s over the same columns, a block of kPipeBlock
+// columns behind, reading the boundary row strip s writes (one row per strip boundary).  Waves claim tickets in the order job,
+// read, strip: a strip's predecessor always holds a lower ticket, i.e. is running or done whenever the strip waits for it -- no
+// deadlock whatever order the hardware starts blocks in.  Every strip drops its checkpoints, the final strip scans the windows
+// and leaves the partial top-2 of its (read, job).
 template <bool STD, int R>
 __device__ __forceinline__ void strip_pipe_task(const StripArgs &a, const StripRead &rd, const int li, const int job, const int sidx, const int lane,
                                                 Exchange &xc) {
@@ -519,14 +375,14 @@ __device__ __forceinline__ void strip_pipe_task(const StripArgs &a, const StripR
     if (sidx == 0) {  // (queries of this path have more than one strip: the first is never the last)
         // (test hook: the dropped strip publishes into a word nobody reads)
         int32_t *pub = (li == a.debug_drop_strip && job == 0) ? reinterpret_cast<int32_t *>(a.ticket + 8) : prog + sidx;
-        strip_sweep<STD, true, false, false, false, R, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0,
-                                                             0.0f, 0, ckp, a.ck_shift, nck, nullptr, pub);
+        strip_sweep<STD, true, false, false, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, bout_c, res, job, 0, 0.0f, 0, ckp, a.ck_shift, nck,
+                                                nullptr, pub);
     } else if (!last)
-        strip_sweep<STD, false, false, false, false, R, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, bout_c, nullptr, res, job, 0,
-                                                              0.0f, 0, ckp, a.ck_shift, nck, prog + sidx - 1, prog + sidx, a.err, a.spin_limit);
+        strip_sweep<STD, false, false, false, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, bout_c, res, job, 0, 0.0f, 0, ckp, a.ck_shift, nck,
+                                                 prog + sidx - 1, prog + sidx, a.err, a.spin_limit);
     else
-        strip_sweep<STD, false, false, false, true, R, true>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, 0,
-                                                             0.0f, 0, ckp, a.ck_shift, nck, prog + sidx - 1, nullptr, a.err, a.spin_limit);
+        strip_sweep<STD, false, false, true, R>(yp, rlen, rlen, qlen, x, lq, rq, lane, xc, bin_c, nullptr, res, job, 0, 0.0f, 0, ckp, a.ck_shift, nck,
+                                                prog + sidx - 1, nullptr, a.err, a.spin_limit);
     if (last && lane == lq) {
         const int64_t o = static_cast<int64_t>(li) * a.n_jobs + job;
         a.p_best[o] = res.top.best;
@@ -571,19 +427,18 @@ __global__ void __launch_bounds__(256, 4) sdtw_strip_pipe_kernel(const StripArgs
 #endif
 }
 
-// Pass 2, CHAINED (one wave per long read, its winning job): the strips are traced from the LAST one upwards, each over its own
+// Pass 2 (one wave per long read, its winning job): the strips are traced from the LAST one upwards, each over its own
 // short range of columns.  Pass 1 kept the last row of every strip (one row per strip boundary), so a strip can be swept on
 // its own: its `row above` is the row pass 1 stored.  What a strip carries is not the start of the whole path but the column b
 // of the row above through which the path ENTERS the strip: a cell of the strip's first row that continues diagonally from
 // column j - 1 or upwards from column j of the row above takes b = j - 1 or j (lane 0's `up` input carries its own column;
 // its diagonal input is the previous step's); every other cell inherits b by the traceback rule of path()
-// (src/cdtw.c:134-146), exactly as the start column is inherited in the unchained pass 2.  The rule is local, so the cells
+// (src/cdtw.c:134-146), exactly as the start column is inherited in pass 2 of the wave kernels.  The rule is local, so the cells
 // (last row of strip s - 1, b_s) are the cells of the reference's path, and strip 0 -- which holds query row 0 -- delivers the
 // start column.  The cell a strip has to reach is known by column AND cost (the winning score for the last strip, the stored
 // row's value for the others), compared bit for bit: a difference between the passes cannot go unnoticed.
 // A strip of r rows is swept from the checkpoint r + 64 columns (or `trace_margin`) in front of its target cell and backs off
-// 1, 2, 4 ... checkpoints while the path enters in front of the restored state: about (2048 + 64 + T/2) columns per strip
-// against (query length + 64 + T/2) for every strip in the unchained pass -- a third of the work at 8 000 events.
+// 1, 2, 4 ... checkpoints while the path enters in front of the restored state: about (2048 + 64 + T/2) columns per strip.
 template <bool STD, int R>
 __device__ __forceinline__ void strip_chain_task(const StripArgs &a, const StripRead &rd, const int li, const int job, const int lane, Exchange &xc) {
     const int qlen = rd.qlen, n_strips = rd.n_strips;
@@ -620,11 +475,11 @@ __device__ __forceinline__ void strip_chain_task(const StripArgs &a, const Strip
             res.cap_end = -1;
             res.cap_st = -1;
             if (sidx == 0)
-                strip_sweep<STD, true, true, true, true, R>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, nullptr, nullptr, nullptr, nullptr, res, job, e,
-                                                            want, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, true, true, true, R>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, nullptr, nullptr, res, job, e, want, k * T, ckp,
+                                                      a.ck_shift, nck);
             else
-                strip_sweep<STD, false, true, true, true, R>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, bin_c, nullptr, nullptr, nullptr, res, job, e,
-                                                             want, k * T, ckp, a.ck_shift, nck);
+                strip_sweep<STD, false, true, true, R>(yp, rlen, e + 1, qlen, x, lq, rq, lane, xc, bin_c, nullptr, res, job, e, want, k * T, ckp,
+                                                       a.ck_shift, nck);
             b = __builtin_amdgcn_readlane(res.cap_st, lq);  // lq: wave-uniform
             hit = __builtin_amdgcn_readlane(res.cap_end, lq);
             if (b >= 0 || k == 0 || hit < 0) break;
@@ -666,15 +521,11 @@ __global__ void __launch_bounds__(256, 1) sdtw_strip_chain_kernel(const StripArg
     SFA_STRIP_DISPATCH(strip_chain_task, rd.qlen, a, rd, li, job, lane, xc)
 }
 
-// instantiated in sdtw_inst_strips.hip
+// instantiated in sdtw_inst_strips_pipe.hip / sdtw_inst_strips_chain.hip
 extern template __global__ void sdtw_strip_chain_kernel<false>(const StripArgs);
 extern template __global__ void sdtw_strip_chain_kernel<true>(const StripArgs);
 extern template __global__ void sdtw_strip_pipe_kernel<false>(const StripArgs);
 extern template __global__ void sdtw_strip_pipe_kernel<true>(const StripArgs);
-extern template __global__ void sdtw_strip_kernel<false, false>(const StripArgs);
-extern template __global__ void sdtw_strip_kernel<true, false>(const StripArgs);
-extern template __global__ void sdtw_strip_kernel<false, true>(const StripArgs);
-extern template __global__ void sdtw_strip_kernel<true, true>(const StripArgs);
 
 struct StripFinalizeArgs {
     const int32_t *reads;  // [n_long]

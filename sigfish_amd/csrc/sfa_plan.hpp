@@ -4,8 +4,7 @@
 // read ranges per thread + work stealing) with a static plan for the GPU:
 //   * reads are grouped four at a time into "quads" (one wavefront each); lengths select a rows-per-lane class R
 //     (4/8/16/32) -- long classes first so that short work fills the tail; inside a class reads whose lengths agree
-//     modulo R share waves (lengths descending; MixedQuad in sdtw_kernels.hpp), std_dtw and the tracking fill keep ONE
-//     length per wave; queries of 513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read
+//     modulo R share waves (lengths descending; MixedQuad in sdtw_kernels.hpp), std_dtw keeps ONE length per wave; queries of 513..1024 / 1025..2048 events take 32 / 64 lanes per read, i.e. two reads / one read
 //     per "quad";
 //   * SMALL BATCHES: when the waves of a batch would not fill the chip, every class trades rows per lane for lanes
 //     per read (R/2 x 2L or R/4 x 4L, "lane widening" 2 or 4): 2-4x the waves, each with a 2-4x shorter step;
@@ -54,7 +53,6 @@ inline int64_t ck_count(int32_t rlen, int shift) { return (rlen > 4 ? rlen - 4 :
 struct PlanParams {
     int64_t n_sims = 1024;          // SIMDs on the device (CUs * 4)
     int64_t waves_per_simd = 6;     // occupancy to aim for when chunking
-    bool single_pass = false;
     int64_t ckpt_interval = 0;      // 0 = auto
     int64_t ckpt_budget_bytes = 32ll << 30;
     int64_t trace_margin = -1;      // -1 = longest query + lanes per read (16 up to 512 events)
@@ -64,9 +62,9 @@ struct PlanParams {
     int64_t widen_below = 5;        // auto: widen (x4) when the batch has fewer than this many waves per SIMD
     int64_t column_segments = 0;    // 0 = auto (small batches of the 64-lane shapes), 1 = off, N = N segments per job
     int64_t segment_warm_windows = 4;  // windows (query lengths) a segment starts before its own first one
-    bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory) and single pass
-    int lds_ckpt = 0;               // 1: rolling checkpoints in LDS + sparse HBM checkpoints (sdtw_kernels.hpp, LdsCkpt) where the shapes allow and the batch size suits; 2: wherever the shapes allow
-    bool mixed_quads = true;        // reads of different lengths (equal modulo the rows per lane) may share a wave (sdtw_kernels.hpp, MixedQuad)
+    bool allow_segments = true;     // false for std_dtw (its first row is cumulative: no finite memory)
+    int lds_ckpt = 0;               // 1: rolling checkpoints in LDS + sparse HBM checkpoints (sdtw_kernels.hpp, LdsCkpt) where the shapes allow (queries up to
+                                    // 256 events: the measured regime) and the batch size suits; 2: wherever the shapes allow (up to 1024 events at 16 rows per lane)
     bool std_dtw = false;           // --dtw-std: with lds_ckpt the fill keeps NO LDS snapshots, only the sparse HBM store (the margin is not capped)
     bool skip_long = false;         // true: reads of more than kMaxQuery events are left out (the caller runs them in row strips, sdtw_strips.hpp)
 };
@@ -80,7 +78,6 @@ struct BatchPlan {
     int32_t n_quads = 0, n_chunks = 1, max_R = 4, max_lanes = 16, widening = 1, ck_shift = 0, trace_margin = 0;
     int32_t lck_shift = 9;  // with lds_ckpt: log2 of the interval between two LDS snapshots (9, 10, 11 for queries up to 256, 512, 1024 events)
     int32_t n_seg = 1, warm_windows = 4;  // column segments per job (sdtw_kernels.hpp, sweep_segment)
-    bool single_pass = false;
     bool lds_ckpt = false;  // the fill keeps its snapshots in LDS; ck_shift is then the interval of the sparse HBM store
     int64_t ck_floats = 0, query_events = 0;
     std::vector<int32_t> order;         // [4*max(n_quads,1)] read per (quad,slot) or -1
@@ -97,7 +94,6 @@ struct BatchPlan {
     void reset() {  // scalars back to their defaults; vectors keep their capacity
         n_quads = 0; n_chunks = 1; max_R = 4; max_lanes = 16; widening = 1; ck_shift = 0; trace_margin = 0; lck_shift = 9;
         n_seg = 1; warm_windows = 4;
-        single_pass = false;
         lds_ckpt = false;
         ck_floats = 0; query_events = 0;
         classes.clear();
@@ -123,7 +119,6 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
                       const PlanParams &pp, BatchPlan *out, std::string *err) {
     BatchPlan &p = *out;
     p.reset();
-    p.single_pass = pp.single_pass;
     const int32_t n_jobs = static_cast<int32_t>(job_len.size());
     std::vector<int32_t> &qlen = p.s_qlen, &count = p.s_count, &fill_pos = p.s_fill_pos;
     qlen.assign(n, 0);
@@ -147,27 +142,15 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     }
     // classes in task order (long first); inside a class by descending length.  layout(w) fills the plan for lane
     // widening w and returns the number of quads (waves' worth of reads).
-    // Queries of 257 .. 1024 events on the LDS-checkpoint route: their base shapes hold 32 rows per lane (16 or 32 lanes per
-    // read), whose snapshots (33 planes) do not fit LDS twice at four waves per SIMD.  The same queries fit 16 rows x 32 / 64
-    // lanes (two reads / one read per wave) -- the shapes of "lane widening" 2 --, which run the 16-row kernels: rolling
-    // snapshots in LDS (every 1024 / 2048 steps instead of 512, so that a window and the head start of pass 2 fit one interval),
-    // pass 2 by ticket in the same launch, and the 3.06-instruction cell of the headline kernel instead of the 32-row step
-    // with its window-cell bookkeeping.  Not for batches that also hold queries beyond 1024 events: those need 32 rows x 64 lanes
-    // and the 32-row kernels anyway.
-    // Measured (profiles/r03_logs/ab_q500_q1000_q700_*.jsonl, ms per step of the same cell count, this route / the 32-row kernels
-    // with every snapshot in HBM and pass 2 as its own launch): q = 500 89.6 / 87.9, q = 700 131.2 / 130.5, q = 1000 95.9 / 94.4 --
-    // the 32-row step is no slower per cell (3.05 VALU per cell against 3.09) and its pass 1 names the winning CELL, so its pass 2
-    // is shorter (4.5 against ~6 ms at q = 500); what this route saves is the 12.6 GB of snapshot stores per launch and three
-    // launches, not time.  It is therefore taken only on request (lds_ckpt = 2); lds_ckpt = 1 keeps the 32-row kernels.
-    const bool r32_as_r16 = pp.lds_ckpt >= 2 && !pp.single_pass && pp.ckpt_interval == 0 && maxq > 256 && maxq <= 1024;
-    auto class_widening = [&](int ci, int w) { return (r32_as_r16 && (ci == 1 || ci == 2)) ? std::max(w, 2) : w; };
+    // (Queries of 257 .. 2048 events keep their 32-row base shapes in large batches: their snapshots -- 33 planes -- do not fit LDS
+    // twice at four waves per SIMD, so they go to HBM and pass 2 rides in the fill launch by ticket.  Running them as 16 rows x 32 /
+    // 64 lanes on the LDS route instead measured 1-2 % slower: LABNOTES.md.)
     // MIXED QUADS (sdtw_kernels.hpp, MixedQuad): reads of different lengths share a wave when their lengths agree modulo the
     // rows per lane R of their class -- every read's last query row then falls into the same lane and register.  A class is laid
     // out residue by residue, lengths descending inside a residue, a new wave only where a residue ends: a ragged batch with a few
-    // hundred distinct lengths leaves at most R partly filled waves per class instead of one per length.  Not for std_dtw and
-    // the tracking fill (their kernels keep one length per wave) nor at lane widening 4 (the column segments align on ONE
-    // query length).
-    auto mixing = [&](int w) { return pp.mixed_quads && !pp.single_pass && !pp.std_dtw && w < 4; };
+    // hundred distinct lengths leaves at most R partly filled waves per class instead of one per length.  Not for std_dtw
+    // (its kernels keep one length per wave) nor at lane widening 4 (the column segments align on ONE query length).
+    auto mixing = [&](int w) { return !pp.std_dtw && w < 4; };
     std::vector<int32_t> &slot_start = p.s_slot_start, &len_quad_base = p.s_len_quad_base;
     slot_start.assign(maxq + 2, 0);
     len_quad_base.assign(maxq + 2, 0);
@@ -176,7 +159,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
         int32_t n_quads = 0;
         const bool mix = mixing(w);
         for (int ci = 0; ci < 6; ++ci) {
-            const ClassShape sh = widened(ci, class_widening(ci, w));
+            const ClassShape sh = widened(ci, w);
             PlanClass cl;
             cl.R = sh.R;
             cl.lanes = sh.lanes;
@@ -239,7 +222,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     per_shift.assign(maxq + 2, 0);  // log2(reads per wave) of every query length that occurs (4, 2 or 1 reads)
     for (int l = 1; l <= maxq; ++l)
         if (count[l]) {
-            const int per = 64 / widened(class_for(l), class_widening(class_for(l), w)).lanes;
+            const int per = 64 / widened(class_for(l), w).lanes;
             per_shift[l] = per == 4 ? 2 : (per == 2 ? 1 : 0);
         }
     for (int32_t i = 0; i < n; ++i) {
@@ -257,7 +240,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
 
     // column segments: when even one wave per (read, job) leaves the chip idle, every job is cut into segments that
     // start from a guessed state a few windows early and are verified against their predecessor (sweep_segment)
-    if (pp.allow_segments && !pp.single_pass && p.widening == 4 && p.max_lanes == 64 && n_quads > 0) {
+    if (pp.allow_segments && p.widening == 4 && p.max_lanes == 64 && n_quads > 0) {
         int32_t min_len = n_jobs ? job_len[0] : 0;
         for (int32_t j = 1; j < n_jobs; ++j) min_len = std::min(min_len, job_len[j]);
         const int64_t tasks = static_cast<int64_t>(n_quads) * n_jobs;
@@ -288,7 +271,7 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // LDS checkpoints: every shape of the batch must hold its state in 17 planes (R <= 16), one sweep per (quad, job); the
     // margin is capped so that the snapshot pass 2 wants for a window is one of the last two (LdsCkpt::save):
     // interval (512 / 1024 / 2048 by the longest query) >= window length + margin + 3
-    p.lds_ckpt = pp.lds_ckpt && !pp.single_pass && pp.ckpt_interval == 0 && p.max_R <= 16 && p.n_seg == 1 && n_quads > 0 && maxq <= 1024;
+    p.lds_ckpt = pp.lds_ckpt && pp.ckpt_interval == 0 && p.max_R <= 16 && p.n_seg == 1 && n_quads > 0 && maxq <= (pp.lds_ckpt >= 2 ? 1024 : 256);
     p.lck_shift = maxq <= 256 ? 9 : (maxq <= 512 ? 10 : 11);
     {   // the LDS buffers cap the fill at four waves per SIMD instead of six: a batch whose tasks are all resident at six
         // but not at four would need a second round (measured: 8 192 reads 7.35 -> 7.65 ms); everything else gains
@@ -300,9 +283,9 @@ inline int plan_batch(const int64_t *q_off, int32_t n, const std::vector<int32_t
     // Snapshots in HBM every 512 steps (the 32-row shapes): a head start that turns out too short costs one more attempt from the
     // snapshot before, so it can follow what alignments actually span (event detection over-segments: ~2/3 of a column per event)
     // instead of a whole query length.  Not on the LDS route: there a miss falls back to the sparse store or the strand's start.
-    if (adapt && !p.lds_ckpt && !pp.single_pass && !pp.std_dtw)
+    if (adapt && !p.lds_ckpt && !pp.std_dtw)
         p.trace_margin = std::min<int32_t>(p.trace_margin, static_cast<int32_t>((static_cast<int64_t>(maxq) * pp.span_sixteenths) / 16) + p.max_lanes + 16);
-    if (!pp.single_pass && n_quads > 0) {
+    if (n_quads > 0) {
         int shift = p.lds_ckpt ? 15 : 9;  // T = 512: measured optimum of fill (+checkpoint stores) against pass 2 (re-run length); sparse store: 32768
         if (pp.ckpt_interval > 0) {
             shift = 0;

@@ -10,17 +10,14 @@ int main(int argc, char **argv) {
     const int max_q = argc > 1 ? atoi(argv[1]) : 400000;
     long bad = 0;
     double worst = 1.0;
-    for (int balanced = 0; balanced <= 1; ++balanced)
-        for (int q = sfa::kStripRows + 1; q <= max_q; ++q) {  // (queries of up to 2048 events never come here)
-            const int n = (q + sfa::kStripRows - 1) / sfa::kStripRows;
-            const int R = sfa::strip_rows_per_lane(q, balanced);
-            const bool ok = (R == 20 || R == 24 || R == 28 || R == 32) && (balanced || R == 32) && 64L * R * n >= q && 64L * R * (n - 1) < q;
-            if (!ok && bad++ < 10) fprintf(stderr, "qlen %d balanced %d: R %d, %d strips\n", q, balanced, R, n);
-            if (balanced) {
-                const double fill = static_cast<double>(q) / (64.0 * R * n);
-                if (fill < worst) worst = fill;
-            }
-        }
+    for (int q = sfa::kStripRows + 1; q <= max_q; ++q) {  // (queries of up to 2048 events never come here)
+        const int n = (q + sfa::kStripRows - 1) / sfa::kStripRows;
+        const int R = sfa::strip_rows_per_lane(q);
+        const bool ok = (R == 20 || R == 24 || R == 28 || R == 32) && 64L * R * n >= q && 64L * R * (n - 1) < q;
+        if (!ok && bad++ < 10) fprintf(stderr, "qlen %d: R %d, %d strips\n", q, R, n);
+        const double fill = static_cast<double>(q) / (64.0 * R * n);
+        if (fill < worst) worst = fill;
+    }
     printf("%ld violations; least filled strips: %.3f of their rows are query rows\n", bad, worst);
     return bad != 0;
 }

@@ -54,25 +54,13 @@ def main():
             opts["ckpt_interval"] = int(rng.choice([4, 8, 16, 64, 256, 1024]))
         if rng.integers(0, 2):
             opts["trace_margin"] = int(rng.choice([0, 3, 50, 300]))
-        if rng.integers(0, 5) == 0:
-            opts["single_pass"] = 1
         if rng.integers(0, 3) == 0:
             opts["lds_ckpt"] = 0  # every snapshot to HBM (default: rolling in LDS where the shapes allow)
-        if rng.integers(0, 3) == 0:
-            opts["strip_pipeline"] = 0  # row strips: one wave per (read, job)
-        if rng.integers(0, 3) == 0:
-            opts["strip_chain"] = 0  # row strips, pass 2: all strips over the whole range
-        if rng.integers(0, 4) == 0:
-            opts["balanced_strips"] = 0  # row strips of 64 x 32 rows and a short last one
-        if rng.integers(0, 4) == 0:
-            opts["long_overlap"] = 0  # row strips behind the wave kernels instead of beside them
         opts["fused_trace"] = int(rng.choice([0, 1, 2, 2]))  # pass 2 as its own launch / by batch size / inside the fill launch
         if rng.integers(0, 4) == 0:
             opts["lds_ckpt"] = 2  # LDS checkpoints whatever the batch size
         if rng.integers(0, 3) == 0:
             opts["prio_unit"] = int(rng.choice([0, 64, 700]))
-        if rng.integers(0, 4) == 0:
-            opts["mixed_quads"] = 0  # one query length per wave (default: lengths equal modulo the rows per lane share waves)
         opts["lane_widening"] = int(rng.choice([0, 1, 1, 2, 4]))  # small batches widen by themselves; pin the other shapes too
         if rng.integers(0, 2):  # column segments (small batches): forced counts and short warm-ups exercise the hand-over check
             opts["column_segments"] = int(rng.choice([1, 2, 3, 8, 16]))

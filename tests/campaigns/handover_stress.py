@@ -69,13 +69,14 @@ def main():
     else:
         ref, flag, pq, poff, _ = synth.workload("ncov_r9_dna_q4000", n_reads=64, seed=seed)
         oref = O.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
-        with S.Aligner(ref, flag) as pipe, S.Aligner(ref, flag) as classic:
-            classic.set_option("strip_pipeline", 0)
+        with S.Aligner(ref, flag) as pipe, S.Aligner(ref, flag) as dense:
+            for k, v in (("ckpt_interval", 64), ("trace_margin", 0)):  # same strips, every strip of pass 2 backs off through its checkpoints
+                dense.set_option(k, v)
             for it in range(iters):
                 n = int(rng.integers(300, 1500))
                 q, q_off = ragged_batch(rng, pq, poff, n, 4000)
                 a = pipe.align_db(q, q_off)
-                b = classic.align_db(q, q_off)
+                b = dense.align_db(q, q_off)
                 ok = a.tobytes() == b.tobytes()
                 if it % 10 == 0:  # (a 4000-event matrix per thread: keep the oracle's share small)
                     want = O.align_batch(q, q_off[:5], oref, flag, threads=4)

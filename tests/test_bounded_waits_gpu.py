@@ -24,8 +24,23 @@ def _same(got, want):
     assert np.array_equal(got["score2"].view(np.uint32), want["score2"].view(np.uint32))
 
 
-def test_a_quad_that_never_publishes_fails_the_batch_instead_of_hanging(oracle):
-    ref, flag, q, q_off, _ = synth.workload("ncov_r9_dna_q250", n_reads=64, seed=3)
+@pytest.fixture(autouse=True)
+def _hooks(monkeypatch):
+    monkeypatch.setenv("SFA_TEST_HOOKS", "1")  # debug_drop_* are refused otherwise (sfa_set_option reads the environment)
+
+
+def test_the_hooks_are_refused_without_the_environment_switch(monkeypatch):
+    monkeypatch.delenv("SFA_TEST_HOOKS")
+    ref, flag, _, _, _ = synth.workload("ncov_r9_dna_q250", n_reads=4, seed=1)
+    with S.Aligner(ref, flag) as al:
+        for key in ("debug_drop_quad", "debug_drop_strip"):
+            with pytest.raises(S.SfaError, match="test hook"):
+                al.set_option(key, 0)
+
+
+@pytest.mark.parametrize("wl", ["ncov_r9_dna_q250", "ncov_r9_dna_q500"])  # the LDS-checkpoint fill / the 32-row fill (snapshots in HBM)
+def test_a_quad_that_never_publishes_fails_the_batch_instead_of_hanging(oracle, wl):
+    ref, flag, q, q_off, _ = synth.workload(wl, n_reads=64, seed=3)
     with S.Aligner(ref, flag) as al:
         for k, v in (("lane_widening", 1), ("lds_ckpt", 2), ("fused_trace", 2), ("spin_limit_ms", 300), ("debug_drop_quad", 0)):
             al.set_option(k, v)

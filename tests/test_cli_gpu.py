@@ -105,15 +105,12 @@ RANDOM_CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(G
 
 
 @pytest.mark.parametrize("name", RANDOM_CASES)
-@pytest.mark.parametrize("extra", [[], ["-K", "7"], ["--host-events"], ["--gpu-parse"], ["--gpu-parse", "-K", "7"], ["--host-parse", "-K", "7"],
-                                   ["--hybrid-parse", "2", "-K", "7"], ["--hybrid-parse", "3", "-K", "3"], ["--hybrid-parse", "0", "-K", "7"],
-                                   ["--host-inflate", "-K", "7"], ["--host-inflate", "--hybrid-parse", "2", "-K", "3"]])
+@pytest.mark.parametrize("extra", [[], ["-K", "7"], ["--host-events"], ["--gpu-parse"], ["--gpu-parse", "-K", "7"], ["--host-parse", "-K", "7"]])
 def test_cli_random_signal_goldens(name, extra, models):
     """Synthetic step signals in compressed BLOW5 files (40 reads each) whose PAF / SAM text the compiled reference
     printed (tests/golden/random, oracle/make_golden.py): the command line must print the same, through device-side and
-    host-side event detection, in one batch and in several, with the records parsed on host threads (--host-parse), on the device
-    (--gpu-parse), batch by batch on either (--hybrid-parse), or inflated on host threads and parsed on the device
-    (--host-inflate)."""
+    host-side event detection, in one batch and in several, with the records parsed on host threads (--host-parse) or on the device
+    (--gpu-parse)."""
     k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
     cmd = [BIN, "dtw", "--kmer-model", models[int(k)], "--verbose", "0", *args, *extra, os.path.join(GOLD, "data", fasta),
            os.path.join(GOLD, "random", blow5)]

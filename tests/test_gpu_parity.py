@@ -27,25 +27,29 @@ def assert_rows_equal(got, want):
     assert np.array_equal(got["score2"][v].view(np.uint32), want["score2"][v].view(np.uint32))
 
 
-# the two-pass default, the single-pass variant, a configuration that forces dense checkpoints + back-off (all three
-# pinned to the throughput shapes, 16 lanes per read), the small-batch shapes (rows per lane / 2 and / 4), and what the
-# planner picks by itself for these small batches
-# "hbm_ckpt": every snapshot of pass 1 in HBM (the round-1 scheme; the default now keeps them in LDS where the shapes allow);
-# "lds_backoff": LDS checkpoints with no head start at all, so that pass 2 must back off to the sparse store / the strand start
-MODES = {"two_pass": {"lane_widening": 1}, "single_pass": {"single_pass": 1, "lane_widening": 1},
-         "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1}, "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2, "fused_trace": 2},
+# Every setting of the options that selects another kernel or another hand-over between pass 1 and pass 2 (include/sigfish_amd.h:
+# rows never depend on options), most pinned to the throughput shapes (16 lanes per read):
+#   two_pass      the defaults at these batch sizes: pass 2 as its own launch, LDS checkpoints where the shapes allow
+#   fused         pass 2 by ticket inside the fill launch whatever the batch size: the LDS-checkpoint fill (<= 16 rows per lane,
+#                 up to 1024 events) and the 32-row fill with its snapshots in HBM
+#   unfused       ... and never
+#   hbm_ckpt      every snapshot of pass 1 in HBM
+#   lds_backoff   LDS checkpoints with no head start at all, so that pass 2 must back off to the sparse store / the strand start
+#   dense_ckpt    snapshots every 32 steps and no head start: every read backs off through several of them
+#   strips_backoff  the same for the row strips of queries beyond 2048 events
+#   wide2 / wide4_dense / lds_wide4_backoff  the small-batch shapes (rows per lane / 2 and / 4)
+#   auto          what the planner picks by itself for these small batches (lane widening, column segments)
+MODES = {"two_pass": {"lane_widening": 1},
+         "fused": {"lds_ckpt": 2, "fused_trace": 2, "lane_widening": 1},
+         "unfused": {"lds_ckpt": 2, "fused_trace": 0, "lane_widening": 1},
+         "hbm_ckpt": {"lds_ckpt": 0, "lane_widening": 1},
+         "hbm_fused": {"lds_ckpt": 0, "fused_trace": 2, "lane_widening": 1},  # (only the 32-row fill carries tickets without LDS checkpoints)
+         "lds_backoff": {"trace_margin": 0, "lane_widening": 1, "lds_ckpt": 2, "fused_trace": 2},
          "lds_wide4_backoff": {"trace_margin": 0, "lane_widening": 4, "column_segments": 1, "lds_ckpt": 2, "fused_trace": 2},
-         "lds_fused": {"lds_ckpt": 2, "fused_trace": 2, "lane_widening": 1},
-         "lds_unfused": {"lds_ckpt": 2, "fused_trace": 0, "lane_widening": 1},
-         "classic_strips": {"strip_pipeline": 0},  # row strips: one wave per (read, job) instead of one per strip
-         "unchained_strips": {"strip_chain": 0},  # row strips, pass 2: all strips over the whole range instead of strip by strip from the last one upwards
-         "classic_unchained_strips": {"strip_pipeline": 0, "strip_chain": 0},  # (two boundary rows in turn, as in round 1)
-         "strips_backoff": {"trace_margin": 0, "ckpt_interval": 64},  # every strip of the chained pass 2 backs off
-         "tall_strips": {"balanced_strips": 0},  # strips of 64 x 32 rows and a short last one instead of equal heights
-         "tall_classic_strips": {"balanced_strips": 0, "strip_pipeline": 0, "strip_chain": 0},
+         "strips_backoff": {"trace_margin": 0, "ckpt_interval": 64},  # every strip of pass 2 backs off
          "dense_ckpt": {"ckpt_interval": 32, "trace_margin": 0, "lane_widening": 1},
          "wide2": {"lane_widening": 2}, "wide4_dense": {"lane_widening": 4, "ckpt_interval": 32, "trace_margin": 0},
-         "wide4_single": {"lane_widening": 4, "single_pass": 1}, "auto": {}}
+         "auto": {}}
 
 
 def _aligner(ref, flag, mode="two_pass"):
@@ -151,8 +155,7 @@ def test_long_queries(oracle, seed, mode, gpu_mode):
     assert_rows_equal(got, want)
 
 
-@pytest.mark.parametrize("gpu_mode", ["two_pass", "single_pass", "dense_ckpt", "auto", "classic_strips", "unchained_strips", "classic_unchained_strips",
-                                      "strips_backoff", "tall_strips", "tall_classic_strips"])
+@pytest.mark.parametrize("gpu_mode", ["two_pass", "fused", "dense_ckpt", "auto", "strips_backoff"])
 @pytest.mark.parametrize("seed", range(4))
 @pytest.mark.parametrize("mode", ["dna", "rna", "rna_std", "rna_inv"])
 def test_row_strips(oracle, seed, mode, gpu_mode):
@@ -209,15 +212,8 @@ def test_row_strips_ncov_and_groups(oracle):
         al.set_option("ckpt_budget_bytes", 1 << 20)  # less than one read's boundary rows: groups of one read
         assert al.align_db(q, q_off).tobytes() == got.tobytes()
         assert al.profile()["fill_launches"] == 1 + 3
-        al.set_option("strip_pipeline", 0)  # one wave per (read, job)
-        assert al.align_db(q, q_off).tobytes() == got.tobytes()
-        al.set_option("strip_chain", 0)  # pass 2 over all strips at once
-        assert al.align_db(q, q_off).tobytes() == got.tobytes()
-        al.set_option("strip_pipeline", 1)
-        assert al.align_db(q, q_off).tobytes() == got.tobytes()
-        al.set_option("strip_chain", 1)
         al.set_option("ckpt_budget_bytes", 16 << 30)
-        for interval, margin in ((64, 0), (4, 3), (4096, -1), (512, 100)):  # ... and the chained pass 2 with all reads in one launch
+        for interval, margin in ((64, 0), (4, 3), (4096, -1), (512, 100)):  # ... and with all reads in one launch
             al.set_option("ckpt_interval", interval)
             al.set_option("trace_margin", margin)
             assert al.align_db(q, q_off).tobytes() == got.tobytes()
@@ -500,7 +496,7 @@ def test_degenerate_and_non_finite_queries_against_the_reference():
     z = np.load(os.path.join(GOLD, "degenerate", "degenerate.npz"))
     ref, flag, _, _, _ = synth.workload("ncov_r9_dna_q250", n_reads=16, seed=2)
     assert "Assertion `len >= 0' failed" in open(os.path.join(GOLD, "degenerate", "reference_on_non_finite.txt")).read()
-    for mode in ("two_pass", "single_pass", "wide4_dense"):
+    for mode in ("two_pass", "fused", "wide4_dense"):
         with _aligner(ref, flag, mode) as al:
             assert_rows_equal(al.align_db(z["queries_finite"], z["q_off"]), z["rows_finite"].view(S.RESULT_DTYPE))
             assert al.profile()["non_finite_reads"] == 0
@@ -554,9 +550,18 @@ def test_options_are_validated():
                          ("no_such_option", 1)):
             with pytest.raises(S.SfaError):
                 al.set_option(key, bad)
-        for key, ok in (("ckpt_interval", 0), ("ckpt_interval", 64), ("single_pass", 1), ("single_pass", 0), ("trace_margin", -1),
-                        ("lane_widening", 0), ("widen_below", 5), ("ev_parallel_prefix", 0), ("ev_parallel_prefix", 1)):
+        for key, ok in (("ckpt_interval", 0), ("ckpt_interval", 64), ("trace_margin", -1), ("trace_margin", 0),
+                        ("lane_widening", 0), ("widen_below", 5), ("ev_parallel", 0), ("ev_parallel", 3)):
             al.set_option(key, ok)
+        # options of earlier rounds that named rejected variants are gone, not silently accepted
+        for key in ("single_pass", "strip_pipeline", "strip_chain", "balanced_strips", "long_overlap", "mixed_quads", "adaptive_margin"):
+            with pytest.raises(S.SfaError, match="unknown option"):
+                al.set_option(key, 1)
+        # the test hooks are not options: refused unless the process asks for them (tests/test_bounded_waits_gpu.py does)
+        import os
+        if os.environ.get("SFA_TEST_HOOKS") != "1":
+            with pytest.raises(S.SfaError, match="test hook"):
+                al.set_option("debug_drop_quad", 0)
 
 
 def test_no_device_fallback_is_loud():
@@ -595,9 +600,13 @@ def test_pass_2_head_start_follows_the_previous_batch(oracle):
         assert_rows_equal(got, oracle.align_batch(q2, off2, _oracle_ref(oracle, ref), flag, threads=16))
         al.align_db(q, q_off)
         assert 500 * 10 // 16 <= al.profile()["trace_margin"] <= 500 + 16  # (whatever those paths spanned: never beyond a whole query)
-        al.set_option("adaptive_margin", 0)
-        al.align_db(q, q_off)
-        assert al.profile()["trace_margin"] == 500 + 16
+        al.set_option("trace_margin", 500 + 16)  # (pinned: a whole query length + lanes, as for a context's first batch)
+        assert al.align_db(q, q_off).tobytes() == first.tobytes() and al.profile()["trace_margin"] == 500 + 16
+        # the same with pass 2 inside the fill launch: its waves keep the histogram of spans themselves
+        al.set_option("trace_margin", -1)
+        al.set_option("fused_trace", 2)
+        assert al.align_db(q, q_off).tobytes() == first.tobytes()
+        assert al.align_db(q, q_off).tobytes() == first.tobytes() and 500 * 10 // 16 <= al.profile()["trace_margin"] < 500 + 16
 
 
 def test_reference_of_32_megabases_against_its_cut_outs():

@@ -41,7 +41,7 @@ def _one(funcs, pattern):
 
 
 def test_the_checker_notices_a_missing_wait_a_plain_store_and_a_missing_acquire(funcs):
-    name, ins = _one(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb0ELb1ELb1E")
+    name, ins = _one(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb1ELb1EE")
     assert I.check_fused_fill(name, ins) == []
     # (a) the wait in front of the completion counter gone (what round 2 shipped)
     no_wait = [(i, a) for i, a in ins if not (i.startswith("s_waitcnt") and "vmcnt(0)" in i)]
@@ -66,7 +66,7 @@ def test_the_checker_notices_a_missing_wait_a_plain_store_and_a_missing_acquire(
 
 
 def test_valu_per_cell_of_the_headline_loop_is_counted_from_the_build(funcs):
-    st = I.fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb0ELb1ELb1E")
+    st = I.fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb1ELb1EE")
     assert st is not None and st["loops"] >= 16  # one steady-state loop per register of the last query row, two unroll depths
     # three arithmetic instructions per cell + the window minimum and loop overhead: 3.0 .. 3.2
     assert 3.0 <= st["valu_per_cell_min"] <= st["valu_per_cell"] <= st["valu_per_cell_max"] <= 3.2, st
@@ -78,11 +78,16 @@ def test_pass_2_of_the_fused_launch_keeps_its_step_loops_free_of_scratch(funcs):
     19 GB and wrote 2.5 GB per launch that way (124 scratch reloads per four steps; found by the PMC pass).
     Pass 2 may spill around its loops (it is a function call with a 128-VGPR budget), not in them."""
     per = I.scratch_in_hot_loops(funcs, r"fused_trace_dispatch")
-    assert len(per) >= 6  # MAXR 4 / 8 / 16, subsequence and std_dtw
-    assert all(v == (0, 0) for v in per.values()), per
-    # ... and the fill kernels of the fused launches not at all
+    assert len(per) >= 7  # MAXR 4 / 8 / 16, subsequence and std_dtw; MAXR 32, subsequence
+    assert all(v == (0, 0) for k, v in per.items() if "ILi32E" not in k), per
+    # the 32-row shapes: costs + start columns are 64 registers, the query rows live in LDS (LdsRows; in registers it was 85 reloads
+    # per four steps); what is left of the bookkeeping spills a little: at most 2 % of a four-step block of ~1 580 instructions
+    big = [v for k, v in per.items() if "ILi32E" in k]
+    assert len(big) == 1 and big[0][0] <= 32 and big[0][1] <= 8, per
+    # ... and the fill kernels of the fused launches not at all (the 32-row one spills around its sweeps like the unfused 32-row
+    # fill does -- never inside a step loop: test_no_cost_only_fill_kernel_touches_scratch_inside_its_step_loops)
     for name, ins in funcs.items():
-        if re.search(r"sdtw_fill_kernelILi\d+ELb0ELb[01]ELb0ELb1ELb1E", name):
+        if re.search(r"sdtw_fill_kernelILi(4|8|16)ELb[01]ELb0ELb[01]ELb1EE", name):
             assert not any(i.startswith("scratch_") for i, _ in ins), name
 
 
@@ -91,7 +96,7 @@ def test_no_cost_only_fill_kernel_touches_scratch_inside_its_step_loops(funcs):
     spill around the sweep (the 32-row shapes do, a handful), never inside the unrolled step loops.  A wrapper lambda around
     the step call was enough to push the headline kernel's state into scratch once (3 GB fetched + 2.6 GB written per launch,
     27 + 15 GB on the 160-contig workload) with the step time unchanged -- only the counters and this check saw it."""
-    per = I.scratch_in_hot_loops(funcs, r"sdtw_fill_kernelILi\d+ELb0E")
+    per = I.scratch_in_hot_loops(funcs, r"sdtw_fill_kernelILi\d+E")
     assert len(per) >= 20, len(per)
     bad = {k: v for k, v in per.items() if v != (0, 0)}
     assert not bad, bad

@@ -107,7 +107,7 @@ def test_parallel_prefix_sums_and_their_fallback():
     raw2 = np.concatenate(raws)
     with S.Aligner(ref, 0) as al:
         rows_par, info_par = al.align_raw(raw2, off2, np.array(scs), 50, 250)
-        al.set_option("ev_parallel_prefix", 0)
+        al.set_option("ev_parallel", 2)  # sequential prefix sums for every read
         rows_seq, info_seq = al.align_raw(raw2, off2, np.array(scs), 50, 250)
     assert rows_par.tobytes() == rows_seq.tobytes() and info_par.tobytes() == info_seq.tobytes()
     for k in (0, 1, 2, 3, 64, 65, 129):  # host stages on a few of each kind
@@ -157,7 +157,7 @@ def test_parallel_peak_picker_and_its_fallback():
     raw2 = np.concatenate(raws)
     with S.Aligner(ref, 0) as al:
         rows_par, info_par, ev_par = al.align_raw(raw2, off2, np.array(scs), 50, 250, return_events=True)
-        al.set_option("ev_parallel_peaks", 0)
+        al.set_option("ev_parallel", 1)  # sequential peak picker for every read
         rows_seq, info_seq, ev_seq = al.align_raw(raw2, off2, np.array(scs), 50, 250, return_events=True)
     assert rows_par.tobytes() == rows_seq.tobytes() and info_par.tobytes() == info_seq.tobytes() and ev_par.tobytes() == ev_seq.tobytes()
     for k in (0, 1, 2, 3, 64, 69):

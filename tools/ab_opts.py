@@ -3,7 +3,7 @@
 rounds of (A: `--steps` steps, B: `--steps` steps), device-resident queries, median step time per side; rows of A and B
 compared byte for byte.
 
-    python tools/ab_opts.py --workload ncov_r9_dna_q250 --reads 8192,16384,100000 --a mixed_quads=0 --b mixed_quads=1"""
+    python tools/ab_opts.py --workload ncov_r9_dna_q250 --reads 8192,16384,100000 --a fused_trace=0 --b fused_trace=2"""
 import argparse
 import os
 import re

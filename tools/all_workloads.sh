@@ -5,7 +5,6 @@ run --workload ncov_r9_dna_q250
 run --workload sequin_r9_rna_q250
 run --workload rna004_fullref_dtwstd_q250
 run --workload r10_dna_1mb_q250 --reads 125000
-run --workload ncov_r9_dna_q250 --opt single_pass=1
 run --workload ncov_r9_dna_q500
 run --workload ncov_r9_dna_q1000
 run --workload ncov_r9_dna_q2000

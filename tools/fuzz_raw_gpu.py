@@ -52,10 +52,7 @@ def main():
         off = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int64)
         cat = np.concatenate(raws) if off[-1] else np.zeros(0, np.int16)
         with S.Aligner(ref, flag) as al:
-            if rng.integers(0, 3) == 0:
-                al.set_option("ev_parallel_prefix", 0)
-            if rng.integers(0, 3) == 0:
-                al.set_option("ev_parallel_peaks", 0)
+            al.set_option("ev_parallel", int(rng.choice([3, 3, 3, 2, 1, 0])))  # wave-per-read prefix sums (bit 0) / peak picker (bit 1), or the sequential kernels
             rows, info, qev = al.align_raw(cat, off, np.array(scs), prefix, query, return_events=True)
             tabs, qs, qe = [], [], []
             for k, r in enumerate(raws):

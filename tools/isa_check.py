@@ -168,8 +168,9 @@ def check_fused_fill(name, ins_list):
         if " sc1" not in ins:
             bad.append(f"{name}: store without sc1 (not write-through): `{ins}` at {addr}")
     # the completion counter: the only atomic add whose value is not used (no sc0); the ticket add returns (sc0)
-    bad += check_producer(ins_list, name, lambda s: _opcode(s).startswith("global_store"),
-                          lambda s: _opcode(s) == "global_atomic_add" and " sc0" not in s)
+    # (a kernel that also holds private-memory accesses addresses global memory with flat_ instructions: same protocol)
+    bad += check_producer(ins_list, name, lambda s: _opcode(s).startswith(("global_store", "flat_store")),
+                          lambda s: _opcode(s) in ("global_atomic_add", "flat_atomic_add") and " sc0" not in s)
     return bad
 
 
@@ -192,7 +193,7 @@ def protocol_violations(funcs):
     bad = []
     seen = {"fused": 0, "pass2": 0, "pipe": 0}
     for name, ins in funcs.items():
-        if re.search(r"sdtw_fill_kernelILi\d+ELb0ELb[01]ELb0ELb1ELb1E", name):  # <MAXR, false, STD, false, LCK, FUSED>
+        if re.search(r"sdtw_fill_kernelILi\d+ELb[01]ELb0ELb[01]ELb1EE", name):  # <MAXR, STD, false, LCK, FUSED>: pass 2 by ticket in the launch
             seen["fused"] += 1
             bad += check_fused_fill(name, ins)
         elif "fused_trace_dispatch" in name:
@@ -336,12 +337,12 @@ def main(argv):
             so = a
     funcs = disassemble(so)
     bad, seen = protocol_violations(funcs)
-    # <MAXR, TRACK, STD, SEG, LCK, FUSED>: the kernels bench.py's workloads run at full batch size
+    # <MAXR, STD, SEG, LCK, FUSED>: the kernels bench.py's workloads run at full batch size
     stats = {"kernels_checked": seen, "violations": bad,
-             "headline_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb0ELb1ELb1E"),
-             "std_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb1ELb0ELb1ELb1E"),
+             "headline_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb0ELb0ELb1ELb1EE"),
+             "std_fill": fill_loop_stats(funcs, r"sdtw_fill_kernelILi16ELb1ELb0ELb1ELb1EE"),
              "scratch_in_pass2_loops_of_the_fused_launch": scratch_in_hot_loops(funcs, r"fused_trace_dispatch"),
-             "fill32": fill_loop_stats(funcs, r"sdtw_fill_kernelILi32ELb0ELb0ELb0ELb0ELb0E", min_cells=128)}  # (its 32-row loops only)
+             "fill32": fill_loop_stats(funcs, r"sdtw_fill_kernelILi32ELb0ELb0ELb0ELb1EE", min_cells=128)}  # (its 32-row loops only)
     text = json.dumps(stats, indent=1)
     if out:
         with open(out, "w") as f:
