@@ -55,6 +55,7 @@ struct Opt {
     int shard_r = 0, shard_n = 1;        // --shard r/G: the records starting in the r-th of G equal byte slices of the file
     int64_t range_a = 0, range_b = -1;   // --read-range A:B: records [A, B) by position in the file (B omitted: to the end)
     bool no_header = false;              // --no-header: no SAM header (every rank but the first of a sharded run)
+    int device_share = 1;                // ranks of a sharded run that were given the same device as this one (a one-GPU rehearsal of --ranks)
     const char *model_file = nullptr;
     const char *pore = nullptr;
     int pore_flag = 0;  // 0 r9, 1 r10, 2 rna004
@@ -252,6 +253,9 @@ int supervise_ranks(Opt &o, double t0) {
             o.shard_n = G;
             o.ranks = 1;
             o.threads = threads_each;
+            int share = 0;
+            for (int q = 0; q < G; ++q) share += o.devices[q % o.devices.size()] == o.devices[r % o.devices.size()];
+            o.device_share = share;
             o.devices = {o.devices[r % o.devices.size()]};
             o.no_header = o.no_header || r > 0;
             return -1;
@@ -519,7 +523,7 @@ static int dtw_run(int argc, char **argv) {
             die(std::string("accelerator init failed: ") + sfa_last_error());
         // the small-batch shapes pay off while ONE batch leaves the chip idle; with s batches in flight per device the
         // threshold (waves per SIMD of a single batch) shrinks accordingly
-        const int per_dev = n_ctx / static_cast<int>(o.devices.size());
+        const int per_dev = n_ctx / static_cast<int>(o.devices.size()) * o.device_share;  // batches in flight on this device, all processes
         if (sfa_set_option(ctxs[j], "widen_below", std::max(1, 5 / per_dev)) != SFA_OK) die(sfa_last_error());
         // SFA_OPTS="name=value,name=value": planner / launch options of the library (sfa_set_option) for experiments from the
         // command line; rows do not depend on them (the library's test hooks are not options: refused here whatever the environment)

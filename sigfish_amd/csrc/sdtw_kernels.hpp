@@ -1161,6 +1161,24 @@ __global__ void __launch_bounds__(256, LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_F
 #undef SFA_SHAPE
 }
 
+// Cost and start column of register rq (wave-uniform) of this lane's rows.  A scalar branch tree over constant indices, not
+// `c[rq]`: the indexed move wants its 32 registers in one aligned block, and where the allocator could not arrange that (one of the
+// three 32-row shapes of pass 2 inside the fill launch) the whole tuple went through scratch, 672 reloads per four steps.  With a
+// DIVERGENT index (rounds 2-3: rq derived from a vector load) the same expression was a chain of R compare + select pairs per step.
+template <int R, int LO = 0, int HI = R, typename CF, typename CI>
+__device__ __forceinline__ void pick_row(const CF &c, const CI &s, const int rq, float &cl, int &sl) {
+    if constexpr (HI - LO == 1) {
+        cl = c[LO];
+        sl = s[LO];
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (rq < MID)
+            pick_row<R, LO, MID>(c, s, rq, cl, sl);
+        else
+            pick_row<R, MID, HI>(c, s, rq, cl, sl);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Pass 2: start-column recovery for each read's winning candidate.  One wave = one quad; each 16-lane row
 // follows its own (job, end column, checkpoint), so the step index is per lane.
@@ -1208,7 +1226,11 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
     const int g = lane & (L - 1);
     const int slot = lane / L;
 
-    const int qlen = a.quad_qlen[quad];  // the longest read of the wave: lane and register of everybody's last query row
+    // the longest read of the wave: lane and register of everybody's last query row.  Wave-uniform, and SAID so: inside the fused
+    // launch the arguments arrive through a pointer in vector registers, the compiler takes everything loaded through it for
+    // divergent, and `c[rq]` with a divergent index is a chain of R compare + select pairs per step (4 v_cndmask per cell instead
+    // of 2 in the shipped pass 2 of rounds 2-3); with a scalar index it is one indexed move
+    const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);
     const int read = a.order[quad * 4 + slot];
     const int lq = (qlen - 1) / R;
     const int rq = (qlen - 1) - lq * R;
@@ -1329,8 +1351,9 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
                     dp_step<R, true, STD, int>(c, s, dprev, sdprev, xl, yv.v[u], t - mq.g0, lane0, xc);
                 else
                     dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t - mq.g0, lane0, xc);  // (the column of the lane holding row 0)
-                const float cl = c[rq];
-                const int sl = s[rq];
+                float cl;
+                int sl;
+                pick_row<R>(c, s, rq, cl, sl);
                 const bool hit = (cap_end < 0) && !bad_rec && (t >= t_first) && (t <= t_last) && (cl == best);
                 cap_end = hit ? (t - lq) : cap_end;
                 cap_st = hit ? sl : cap_st;
@@ -1443,7 +1466,7 @@ __device__ __forceinline__ void fused_trace_task(const DpArgs &a, const ClassDes
         if (lane == 0) report_device_error(a.err, kErrQuadWait, quad, seen);
         return;  // wave-uniform; the host reports SFA_EKERNEL for the batch
     }
-    const int qlen = a.quad_qlen[quad];
+    const int qlen = __builtin_amdgcn_readfirstlane(a.quad_qlen[quad]);
     const int lq = (qlen - 1) / R;
     const int read = a.order[quad * 4 + slot];
     const bool owner = (g == lq) && read >= 0;
