@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step (default 100 000 at -q 250, same cell count otherwise)")
     ap.add_argument("--workload", default="ncov_r9_dna_q250")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-reads", type=int, default=None,
+                    help="fixed size of the CPU baseline's sample instead of a time target (BASELINE.md section 3: 2048 / 64 / 1024 reads for configs 3 / 4 / 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-buffers", action="store_true",
                     help="also time sfa_align_batch with HOST query/result buffers (PCIe-inclusive; never `value`)")
@@ -370,9 +372,12 @@ def main():
             rows = O.align_batch(q, q_off[:m + 1], oref, flag, threads=cores)
             return rows, time.perf_counter() - t1
 
-        pilot = min(n, cores * 4)
-        _, pdt = cpu_run(pilot)
-        sample = int(max(pilot, min(n, pilot / pdt * args.cpu_seconds)))
+        if args.cpu_reads is not None:
+            sample = max(1, min(n, args.cpu_reads))
+        else:
+            pilot = min(n, cores * 4)
+            _, pdt = cpu_run(pilot)
+            sample = int(max(pilot, min(n, pilot / pdt * args.cpu_seconds)))
         want, dt = cpu_run(sample)
         last = ((args.steps - 1) % n_slots) * row_bytes
         got = np.frombuffer(d_out[last:last + row_bytes].cpu().numpy().tobytes(), dtype=S.RESULT_DTYPE)[:sample]

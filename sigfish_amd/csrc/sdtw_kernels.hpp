@@ -1161,10 +1161,11 @@ __global__ void __launch_bounds__(256, LCK ? SFA_LCK_WAVES : (MAXR <= 16 ? SFA_F
 #undef SFA_SHAPE
 }
 
-// Cost and start column of register rq (wave-uniform) of this lane's rows.  A scalar branch tree over constant indices, not
-// `c[rq]`: the indexed move wants its 32 registers in one aligned block, and where the allocator could not arrange that (one of the
-// three 32-row shapes of pass 2 inside the fill launch) the whole tuple went through scratch, 672 reloads per four steps.  With a
-// DIVERGENT index (rounds 2-3: rq derived from a vector load) the same expression was a chain of R compare + select pairs per step.
+// Cost and start column of register rq (wave-uniform) of this lane's rows, for the 32-row shapes: a scalar branch tree over constant
+// indices, not `c[rq]`.  The indexed move wants its 32 registers in one aligned block, and where the allocator could not arrange
+// that (one of the three 32-row shapes of pass 2 inside the fill launch) the whole tuple went through scratch, 672 reloads per four
+// steps: 276 ms per step instead of 79.5 at q = 500.  Shapes of up to 16 rows per lane take the indexed move (76.6 -> 75.8 ms on the
+// headline against the select chain a DIVERGENT index gave in rounds 2-3; the tree: 76.2).  profiles/r04_logs/ab_pass2_last_row_pick.log
 template <int R, int LO = 0, int HI = R, typename CF, typename CI>
 __device__ __forceinline__ void pick_row(const CF &c, const CI &s, const int rq, float &cl, int &sl) {
     if constexpr (HI - LO == 1) {
@@ -1353,7 +1354,12 @@ __device__ __forceinline__ void trace_core(const DpArgs &a, const ClassDesc cd, 
                     dp_step<R, true, STD, int>(c, s, dprev, sdprev, x, yv.v[u], t - mq.g0, lane0, xc);  // (the column of the lane holding row 0)
                 float cl;
                 int sl;
-                pick_row<R>(c, s, rq, cl, sl);
+                if constexpr (R >= 32) {
+                    pick_row<R>(c, s, rq, cl, sl);
+                } else {  // one indexed move each (s_set_gpr_idx): rq is a scalar
+                    cl = c[rq];
+                    sl = s[rq];
+                }
                 const bool hit = (cap_end < 0) && !bad_rec && (t >= t_first) && (t <= t_last) && (cl == best);
                 cap_end = hit ? (t - lq) : cap_end;
                 cap_st = hit ? sl : cap_st;

@@ -49,16 +49,20 @@ def test_only_a_profile_of_this_build_workload_size_and_options_is_quoted(tmp_pa
 
 
 def test_every_baseline_configuration_has_a_committed_profile():
-    """profiles/r03_*: kernel statistics + PMC summary + meta for the five workload shapes DESIGN.md section 4 tabulates."""
+    """profiles/<newest round>_*: kernel statistics + PMC summary + meta for the workload shapes DESIGN.md section 4 tabulates, all
+    taken on one build in one call (tools/profile_all.sh)."""
+    import re
     B = _bench()
     want = {"ncov_r9_dna_q250": 100000, "sequin_r9_rna_q250": 100000, "rna004_fullref_dtwstd_q250": 100000, "r10_dna_1mb_q250": 125000,
             "ncov_r9_dna_q1000": 25000}
+    names = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_.*_meta\.json$", f)]
+    newest = max(int(re.match(r"r(\d+)_", f).group(1)) for f in names)
     metas = {}
-    for f in os.listdir(os.path.join(ROOT, "profiles")):
-        if f.startswith("r03_") and f.endswith("_meta.json"):
+    for f in names:
+        if f.startswith("r%02d_" % newest):
             m = json.load(open(os.path.join(ROOT, "profiles", f)))
             metas[m["workload"]] = (f[:-len("_meta.json")], m)
-    assert set(want) <= set(metas), set(want) - set(metas)
+    assert newest >= 4 and set(want) <= set(metas), (newest, set(want) - set(metas))
     builds = {m["build_id"] for _, m in metas.values()}
     assert len(builds) == 1  # one call, one build
     for wl, reads in want.items():
