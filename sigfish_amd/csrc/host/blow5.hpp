@@ -54,6 +54,7 @@ class Blow5Reader {
     // first value (read group 0) of a header attribute, or nullptr (slow5_hdr_get(attr, 0, hdr))
     const char *attr(const std::string &key) const;
     uint32_t num_read_groups() const { return n_groups_; }
+    bool mapped() const { return map_ != nullptr; }           // next_view() works (regular file, mmap succeeded)
     bool records_zlib() const { return record_press_ == 1; }  // the whole record is a zlib stream
     bool signal_svb() const { return signal_press_ == 1; }    // the signal is StreamVByte of zig-zag deltas
     const std::string &error() const { return err_; }
