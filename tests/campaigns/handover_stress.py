@@ -6,10 +6,12 @@ publish / acquire mistake hides (a stale line needs a busy memory system and a c
 are full-size and ragged: thousands of wave-tasks, pass-2 tickets claimed while fill tasks still drain.  Each iteration runs
 the SAME batch through the fused launch (pass 2 inside, hand-over through write-through stores + counters) and through the
 separate launches (kernel boundaries in between: no in-launch hand-over at all) and compares the rows byte for byte; a slice
-of every batch is also checked against the oracle.  `strips` mode does the same for the pipelined row strips (one wave per
-strip following the strip above) against the classic ones (one wave per (read, job)).
+of every batch is also checked against the oracle.  `fused32` does the same for the 32-row fill (queries of 257 .. 2048 events:
+snapshots stored write-through to HBM, pass 2 by ticket with its query rows in LDS); `strips` runs the pipelined row strips (one
+wave per strip following the strip above) twice, with default and with dense checkpoints and no head start (pass 2 backs off
+through them), against each other and the oracle.
 
-Usage: python tests/campaigns/handover_stress.py [iterations] [seed] [fused|strips]"""
+Usage: python tests/campaigns/handover_stress.py [iterations] [seed] [fused|fused32|strips]"""
 import os
 import sys
 import time
@@ -65,6 +67,37 @@ def main():
                     diff = np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(a, b)])[0]
                     print(f"MISMATCH it={it} n={n} margin={margin} rows={diff[:8]} ({len(diff)} differ)", flush=True)
                 if (it + 1) % 10 == 0:
+                    print(f"  {it + 1} iterations, {bad} mismatching batches, {time.time() - t0:.0f} s", flush=True)
+    elif what == "fused32":
+        pools = {}
+        for qmax in (500, 1000, 2000):
+            ref, flag, pq, poff, _ = synth.workload(f"ncov_r9_dna_q{qmax}", n_reads=1024, seed=seed)
+            pools[qmax] = (pq, poff)
+        oref = O.RefSynth(ref.names, ref.seq_lengths, ref.ref_lengths, ref.st_offset, ref.forward, ref.reverse)
+        with S.Aligner(ref, flag) as fused, S.Aligner(ref, flag) as plain:
+            plain.set_option("fused_trace", 0)
+            fused.set_option("fused_trace", 2)
+            for it in range(iters):
+                qmax = int(rng.choice([500, 1000, 2000]))
+                pq, poff = pools[qmax]
+                # more wave-tasks than the chip holds at once (4 096 waves): 4 / 2 / 1 reads per wave, two strands
+                n = int(rng.integers(3000, 9000)) * (4 if qmax == 500 else (2 if qmax == 1000 else 1))
+                q, q_off = ragged_batch(rng, pq, poff, n, qmax)
+                margin = int(rng.choice([-1, -1, -1, 0, 40]))  # 0 / 40: pass 2 backs off through the snapshots
+                for al in (fused, plain):
+                    al.set_option("trace_margin", margin)
+                a = fused.align_db(q, q_off)
+                assert fused.profile()["trace_ms"] < 0.05  # (no launch of its own: pass 2 ran inside the fill launch)
+                b = plain.align_db(q, q_off)
+                ok = a.tobytes() == b.tobytes()
+                m = 24
+                want = O.align_batch(q, q_off[:m + 1], oref, flag, threads=16)
+                ok = ok and a[:m].tobytes() == want.tobytes()
+                if not ok:
+                    bad += 1
+                    diff = np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(a, b)])[0]
+                    print(f"MISMATCH it={it} qmax={qmax} n={n} margin={margin} rows={diff[:8]} ({len(diff)} differ)", flush=True)
+                if (it + 1) % 5 == 0:
                     print(f"  {it + 1} iterations, {bad} mismatching batches, {time.time() - t0:.0f} s", flush=True)
     else:
         ref, flag, pq, poff, _ = synth.workload("ncov_r9_dna_q4000", n_reads=64, seed=seed)

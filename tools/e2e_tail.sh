@@ -9,11 +9,14 @@ with open("/dev/shm/sfa_tail/syn6.model", "w") as f:
         f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
 PY
 cat $D/c.blow5 > /dev/null
-for rep in 1 2 3; do
+# KS="4096 8192" EXTRA="--streams 3": batch sizes / further options to sweep (each REPS times, interleaved)
+for rep in $(seq 1 ${REPS:-3}); do
+for K in ${KS:-4096}; do
 T0=$(date +%s.%N)
-sigfish_amd/bin/sigfish-amd dtw --kmer-model $D/syn6.model -t 16 -B 2G -K 4096 --verbose 4 tests/golden/data/nCoV-2019.reference.fasta $D/c.blow5 > $D/out.paf 2> $D/err.txt
+sigfish_amd/bin/sigfish-amd dtw --kmer-model $D/syn6.model -t ${T:-16} -B 2G -K $K $EXTRA --verbose 4 tests/golden/data/nCoV-2019.reference.fasta $D/c.blow5 > $D/out.paf 2> $D/err.txt
 T1=$(date +%s.%N)
-python -c "print('wall %.3f' % ($T1-$T0))"
+python -c "print('-K $K $EXTRA: wall %.3f' % ($T1-$T0))"
 grep "initialised\|all output\|released\|Data\|waited" $D/err.txt
+done
 done
 rm -rf $D
