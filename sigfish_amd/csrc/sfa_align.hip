@@ -124,7 +124,9 @@ void launch_trace_lck(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, 
 // names each read's winning (job, cell, score); pass 2, one wave per read, traces the winning job strip by strip from the last
 // one upwards with start-column tracking.  Runs on `st`: the context's second stream, beside the wave kernels of the batch; it
 // writes the rows of these reads, which the wave kernels' finalize leaves alone.  Reads are taken in groups whose boundary rows
-// and checkpoints fit the checkpoint budget.
+// and checkpoints fit the checkpoint budget -- and, when there are enough of them, in at least two to four groups that ALTERNATE
+// between two streams and two sets of scratch: pass 2 of a group is one wave per read (0.8 waves per SIMD for 3 125 reads: bound by
+// one wave's dependent chain, 12 ms at 8 000 events), which hides under the next group's pass 1 instead of following the last one.
 int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const int64_t *q_off_host, const std::vector<int32_t> &reads, int64_t max_qlen,
                ResultRow *d_out, hipStream_t st) {
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
@@ -167,14 +169,23 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
     // cost rows of every job, one per strip boundary (pass 1 writes them, pass 2 reads them) + the checkpoints
     const int64_t cost_rows = std::max<int64_t>(1, max_strips - 1);
     const int64_t bytes_per_read = per * cost_rows * 4 + ck_floats_per_read * 4;
-    const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(n_long, c->opt_ckpt_budget / std::max<int64_t>(bytes_per_read, 1))));
+    int64_t waves_total = 0;
+    for (int32_t i = 0; i < n_long; ++i) waves_total += static_cast<int64_t>(n_strips_of[i]) * n_jobs;
+    // every group at least two rounds of the device's wave slots (16 per CU), so that its pipeline of strips still fills the chip
+    const int64_t want_groups = std::max<int64_t>(1, std::min<int64_t>(4, waves_total / (2 * 16 * static_cast<int64_t>(c->cu_count))));
+    const int64_t by_budget = c->opt_ckpt_budget / (2 * std::max<int64_t>(bytes_per_read, 1));  // (two sets of scratch)
+    const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>((n_long + want_groups - 1) / want_groups, by_budget)));
+    const bool two_sets = group < n_long;
     const size_t n_part = static_cast<size_t>(n_long) * n_jobs;
+    const size_t prog_bytes = sizeof(int32_t) * static_cast<size_t>(group) * n_jobs * max_strips;
+    const size_t bndc_floats = static_cast<size_t>(cost_rows) * per * group, lck_floats = static_cast<size_t>(std::max<int64_t>(ck_floats_per_read, 1)) * group;
+    const int sets = two_sets ? 2 : 1;
     const size_t bndc_cap = c->d_bndc.cap;
-    if ((rc = c->d_lprog.reserve(sizeof(int32_t) * static_cast<size_t>(group) * n_jobs * max_strips)) || (rc = c->d_lticket.reserve(64))) return rc;
-    if ((rc = c->d_bndc.reserve(sizeof(float) * cost_rows * per * group)) ||
+    if ((rc = c->d_lprog.reserve(prog_bytes * sets)) || (rc = c->d_lticket.reserve(128))) return rc;
+    if ((rc = c->d_bndc.reserve(sizeof(float) * bndc_floats * sets)) ||
         (rc = c->d_lbest.reserve(4 * n_part)) || (rc = c->d_lsecond.reserve(4 * n_part)) || (rc = c->d_lend.reserve(4 * n_part)) ||
         (rc = c->d_lwin.reserve(4 * 5 * static_cast<size_t>(n_long))) ||
-        (rc = c->d_lck.reserve(sizeof(float) * std::max<int64_t>(ck_floats_per_read, 1) * group)))
+        (rc = c->d_lck.reserve(sizeof(float) * lck_floats * sets)))
         return rc;
     if (c->d_bndc.cap != bndc_cap) HIP_TRY(hipMemsetAsync(c->d_bndc.p, 0x7f, c->d_bndc.cap, st));  // fresh allocation: 3.4e38 everywhere (see the pad note in sdtw_strips.hpp)
     {  // the prefix sums of every group, each in its own words: one upload for all groups, no host wait between them
@@ -190,8 +201,15 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
     const char *ds = c->d_long.as<char>();
     const bool std_dtw = (c->flag & SFA_DTW) != 0;
     int32_t *win = c->d_lwin.as<int32_t>();  // [5][n_long]: w_job, w_ws, w_score, t_st, t_end
+    hipStream_t const first = st;
+    if (two_sets) {  // the second stream starts behind the staging upload (and whatever `first` waited for)
+        HIP_TRY(hipEventRecord(c->lev[2], first));
+        HIP_TRY(hipStreamWaitEvent(c->stream_long2, c->lev[2], 0));
+    }
     for (int32_t g0 = 0, gi = 0; g0 < n_long; g0 += group, ++gi) {
         const int32_t gn = std::min(group, n_long - g0);
+        const int set = two_sets ? (gi & 1) : 0;  // groups of one set run on one stream: its scratch is free when the next one starts
+        st = set ? c->stream_long2 : first;
         sfa::StripArgs sa{};
         sa.queries = d_queries;
         sa.q_off = d_q_off;
@@ -200,7 +218,7 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.job_off = c->d_job_off.as<int64_t>();
         sa.job_len = c->d_job_len.as<int32_t>();
         sa.bnd_off = reinterpret_cast<const int64_t *>(ds + o_bnd);
-        sa.bnd_cost = c->d_bndc.as<float>();
+        sa.bnd_cost = c->d_bndc.as<float>() + set * bndc_floats;
         sa.bnd_stride = cost_rows * per;
         sa.p_best = c->d_lbest.as<float>() + static_cast<size_t>(g0) * n_jobs;
         sa.p_second = c->d_lsecond.as<float>() + static_cast<size_t>(g0) * n_jobs;
@@ -210,7 +228,7 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         sa.w_score = reinterpret_cast<const float *>(win + 2 * static_cast<size_t>(n_long) + g0);
         sa.t_st = win + 3 * static_cast<size_t>(n_long) + g0;
         sa.t_end = win + 4 * static_cast<size_t>(n_long) + g0;
-        sa.ck = c->d_lck.as<float>();
+        sa.ck = c->d_lck.as<float>() + set * lck_floats;
         sa.ck_off = reinterpret_cast<const int64_t *>(ds + o_ck);
         sa.ck_shift = ck_shift;
         sa.max_strips = max_strips;
@@ -246,11 +264,11 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         const dim3 grid2((gn + 3) / 4);
         {  // pass 1: one wave per (job, read, strip), tickets in that order
             const int32_t *soff = reinterpret_cast<const int32_t *>(hs + o_soff) + g0 + gi;  // (uploaded with the staging area, before the loop)
-            HIP_TRY(hipMemsetAsync(c->d_lprog.p, 0, sizeof(int32_t) * static_cast<size_t>(gn) * n_jobs * max_strips, st));
-            HIP_TRY(hipMemsetAsync(c->d_lticket.p, 0, 4, st));
+            sa.progress = reinterpret_cast<int32_t *>(c->d_lprog.as<char>() + set * prog_bytes);
+            sa.ticket = c->d_lticket.as<unsigned>() + set * 16;  // (words 8.. of a set's 64 bytes: where a dropped strip publishes, see strip_pipe_task)
+            HIP_TRY(hipMemsetAsync(sa.progress, 0, sizeof(int32_t) * static_cast<size_t>(gn) * n_jobs * max_strips, st));
+            HIP_TRY(hipMemsetAsync(sa.ticket, 0, 4, st));
             sa.strip_off = reinterpret_cast<const int32_t *>(ds + o_soff) + g0 + gi;
-            sa.progress = c->d_lprog.as<int32_t>();
-            sa.ticket = c->d_lticket.as<unsigned>();
             const int64_t waves = static_cast<int64_t>(soff[gn]) * n_jobs;
             const dim3 gridp(static_cast<unsigned>((waves + 3) / 4));
 #ifdef SFA_TASK_TIMES
@@ -276,6 +294,10 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
         hipLaunchKernelGGL(sfa::sdtw_strip_finalize_kernel, fgrid, fblock, 0, st, fa);
         KERNEL_TRY();
         c->prof.fill_launches++;
+    }
+    if (two_sets) {  // whoever waits for `first` waits for both
+        HIP_TRY(hipEventRecord(c->lev[3], c->stream_long2));
+        HIP_TRY(hipStreamWaitEvent(first, c->lev[3], 0));
     }
     return SFA_OK;
 }
@@ -525,6 +547,7 @@ int sfa::align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, 
         c->prof.fill_launches = 0;  // (counted per group of long reads inside)
         if ((rc = align_long(c, d_queries, da.q_off, q_off, long_reads, long_max, d_out, ls))) {
             (void)hipStreamSynchronize(ls);  // nothing of a failed call may still be running when the caller reuses its buffers
+            (void)hipStreamSynchronize(c->stream_long2);
             return rc;
         }
         long_launches = c->prof.fill_launches;

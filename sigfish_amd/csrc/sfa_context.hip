@@ -102,6 +102,7 @@ static int create_context(sfa_ctx **out, const HostRef &h, uint32_t flag, int de
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
     if (hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&c->stream_long2, hipStreamNonBlocking) != hipSuccess) return bail(fail(SFA_ENODEV, "hipStreamCreate failed"));
     for (auto &e : c->lev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(SFA_ENODEV, "hipEventCreate failed"));
     for (auto &e : c->ev)
@@ -198,6 +199,7 @@ void sfa_destroy(sfa_ctx_t *c) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->lev)
         if (e) (void)hipEventDestroy(e);
+    if (c->stream_long2) (void)hipStreamDestroy(c->stream_long2);
     if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

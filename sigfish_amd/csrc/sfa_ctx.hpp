@@ -183,7 +183,8 @@ struct sfa_ctx {
     uint32_t flag = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_long = nullptr;       // the row strips of long queries run beside the wave kernels of the same batch
-    hipEvent_t lev[2] = {nullptr, nullptr};  // inputs of the batch ready on `stream` / strips done on `stream_long`
+    hipStream_t stream_long2 = nullptr;      // ... their groups alternating between two streams (pass 2 of one under pass 1 of the next)
+    hipEvent_t lev[4] = {nullptr, nullptr, nullptr, nullptr};  // inputs of the batch ready on `stream` / strips done on `stream_long` / fork and join of `stream_long2`
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // fill start/end, finalize1 end, trace end, end, row strips start
     hipEvent_t eev[4] = {nullptr, nullptr, nullptr, nullptr};  // sfa_align_raw: event detection start/end, normalisation start/end
     bool eev_pending = false;
