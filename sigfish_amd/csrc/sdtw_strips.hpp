@@ -91,9 +91,9 @@ constexpr int kPipeBlock = SFA_PIPE_BLOCK;  // columns between two hand-overs of
 
 // One anti-diagonal step of a strip: dp_step<R, TRACK> with the handling of query row 0 made conditional on FIRST (the
 // strip that contains it).
-template <bool STD, bool FIRST, bool TRACK, int R>
+template <bool STD, bool FIRST, bool TRACK, int R, typename XT>
 __device__ __forceinline__ void strip_step(typename Vec<float, R>::type &c, typename Vec<int, R>::type &s, float &dprev,
-                                           int &sdprev, const float (&x)[R], const float yv, const int t, const bool lane0,
+                                           int &sdprev, const XT &x, const float yv, const int t, const bool lane0,
                                            Exchange &xc, const float bup = 0.0f, const int bsup = 0) {
     // bup / bsup (wave-uniform; strips below the first): the cell above lane 0's first row, from the boundary row in HBM
     float up = xc.shift(static_cast<float>(c[R - 1]));
@@ -154,9 +154,9 @@ struct StripResult {
 
 // One strip over columns [0, ncols) of one (contig,strand).  LAST: the strip holds the last query row (lane lq,
 // register rq) -- in pass 2 (TRACK) always: the row of the cell to reach.  Pass 2: column ws is the cell to reach, `best` its cost.
-template <bool STD, bool FIRST, bool TRACK, bool LAST, int R>
+template <bool STD, bool FIRST, bool TRACK, bool LAST, int R, typename XT>
 __device__ __forceinline__ void strip_sweep(const float *yp, const int rlen, const int ncols, const int qlen,
-                                            const float (&x)[R], const int lq, const int rq, const int lane, Exchange &xc,
+                                            const XT &x, const int lq, const int rq, const int lane, Exchange &xc,
                                             const float *bin_c, float *bout_c, StripResult &res,
                                             const int job, const int ws, const float best, const int t_begin, float *ckp,
                                             const int ck_shift, const int nck, const int32_t *prog_in = nullptr, int32_t *prog_out = nullptr,
@@ -333,6 +333,8 @@ __device__ __forceinline__ void strip_rows(const StripArgs &a, const StripRead &
         x[r] = (i < rd.qlen) ? rd.q[src] : 0.0f;
     }
 }
+// (Pass 2 keeps its rows in registers: 199 VGPRs, two waves per SIMD.  With the rows in LDS -- 168 VGPRs, three waves -- it was 2.3x
+// slower, 107.6 against 99.2 ms per step at 8 000 events: profiles/r04_logs/rejected_strip_pass2_rows_in_lds_three_waves.log.)
 // the kernels pick the body for the read's rows per lane (wave-uniform)
 #define SFA_STRIP_DISPATCH(BODY, qlen, ...)                    \
     switch (strip_rows_per_lane(qlen)) {                      \

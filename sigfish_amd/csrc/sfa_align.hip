@@ -124,9 +124,11 @@ void launch_trace_lck(int maxr, bool std_dtw, const DpArgs &a, int32_t *out_st, 
 // names each read's winning (job, cell, score); pass 2, one wave per read, traces the winning job strip by strip from the last
 // one upwards with start-column tracking.  Runs on `st`: the context's second stream, beside the wave kernels of the batch; it
 // writes the rows of these reads, which the wave kernels' finalize leaves alone.  Reads are taken in groups whose boundary rows
-// and checkpoints fit the checkpoint budget -- and, when there are enough of them, in at least two to four groups that ALTERNATE
-// between two streams and two sets of scratch: pass 2 of a group is one wave per read (0.8 waves per SIMD for 3 125 reads: bound by
-// one wave's dependent chain, 12 ms at 8 000 events), which hides under the next group's pass 1 instead of following the last one.
+// and checkpoints fit the checkpoint budget -- and, when there are enough of them, in two groups on two streams with two sets of
+// scratch: pass 2 of a group is one wave per read (0.8 waves per SIMD for 3 125 reads: bound by one wave's dependent chain, 12 ms
+// at 8 000 events) and runs beside the other group's work instead of behind everything.  Measured on one box, ms per step at
+// 3 000 / 8 000 events: one group 99.9 / 103.5, two 97.4 / 99.2, four 104.7 / 118.8 (more drains than they hide):
+// profiles/r04_logs/strips_groups_ab*.log, rejected_strip_pass2_rows_in_lds_three_waves.log.
 int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const int64_t *q_off_host, const std::vector<int32_t> &reads, int64_t max_qlen,
                ResultRow *d_out, hipStream_t st) {
     const int32_t n_long = static_cast<int32_t>(reads.size()), n_jobs = c->n_jobs;
@@ -171,8 +173,8 @@ int align_long(sfa_ctx *c, const float *d_queries, const int64_t *d_q_off, const
     const int64_t bytes_per_read = per * cost_rows * 4 + ck_floats_per_read * 4;
     int64_t waves_total = 0;
     for (int32_t i = 0; i < n_long; ++i) waves_total += static_cast<int64_t>(n_strips_of[i]) * n_jobs;
-    // every group at least two rounds of the device's wave slots (16 per CU), so that its pipeline of strips still fills the chip
-    const int64_t want_groups = std::max<int64_t>(1, std::min<int64_t>(4, waves_total / (2 * 16 * static_cast<int64_t>(c->cu_count))));
+    // two groups when each still has two rounds of the device's wave slots (16 per CU) to fill the chip with its pipeline of strips
+    const int64_t want_groups = waves_total >= 4 * 16 * static_cast<int64_t>(c->cu_count) ? 2 : 1;
     const int64_t by_budget = c->opt_ckpt_budget / (2 * std::max<int64_t>(bytes_per_read, 1));  // (two sets of scratch)
     const int32_t group = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>((n_long + want_groups - 1) / want_groups, by_budget)));
     const bool two_sets = group < n_long;
