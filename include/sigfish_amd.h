@@ -157,7 +157,8 @@ int sfa_align_batch_device(sfa_ctx_t *ctx, const float *d_queries, const int64_t
  * (the overlap the reference's strictly serial load -> process -> output loop, src/dtw_main.c:299-326, lacks).
  * sfa_submit_batch returns once the work is queued; `queries` must stay valid until sfa_wait_batch, which blocks,
  * fills out[n_reads] and must be called with the same n_reads.  One batch in flight per context: a second submit
- * waits for the first to finish and discards its rows.  sfa_align_batch == submit + wait. */
+ * waits for the first to finish and discards its rows (if that batch failed on the device, SFA_EKERNEL, the second
+ * submit returns its error).  sfa_align_batch == submit + wait. */
 int sfa_submit_batch(sfa_ctx_t *ctx, const float *queries, const int64_t *q_off, int32_t n_reads);
 int sfa_wait_batch(sfa_ctx_t *ctx, sfa_result_t *out, int32_t n_reads);
 
