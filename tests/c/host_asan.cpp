@@ -81,11 +81,32 @@ int main(int argc, char **argv) {
         const int16_t *raw;
         int64_t n;
         int rc;
+        // a third of the damaged files are read as one rank of a sharded run would: the walk over the size prefixes to the
+        // shard's / range's first record must stay inside the file whatever the prefixes say
+        if (it % 3 == 1) (void)sfa_blow5_select_shard(f, static_cast<int32_t>(rng() % 4), 4);
+        if (it % 3 == 2) (void)sfa_blow5_select_records(f, static_cast<int64_t>(rng() % 6), (rng() & 1) ? -1 : static_cast<int64_t>(rng() % 4));
         while ((rc = sfa_blow5_next(f, &id, meta, &raw, &n)) == 1) {
         }
         if (rc < 0) ++rejected;
         sfa_blow5_close(f);
     }
+    // the shards of an intact file: every record exactly once (counts; contents are compared in tests/test_blow5_shards.py)
+    for (int a = 2; a < argc; ++a)
+        for (int G : {1, 2, 3, 7, 64}) {
+            long got = 0, whole = 0;
+            for (int r = -1; r < G; ++r) {
+                sfa_blow5_t *f = sfa_blow5_open(argv[a]);
+                if (!f) return 12;
+                if (r >= 0 && sfa_blow5_select_shard(f, r, G) != 0) return 13;
+                const char *id;
+                double meta[4];
+                const int16_t *raw;
+                int64_t n;
+                while (sfa_blow5_next(f, &id, meta, &raw, &n) == 1) ++(r < 0 ? whole : got);
+                sfa_blow5_close(f);
+            }
+            if (got != whole || whole == 0) return 14;
+        }
     // the reader's threads inflate records two at a time (sfa_inflate_zlib_pair): pairs of the file's own records, one or both
     // damaged (flipped bits, truncation, random tails), into generous and into too-small buffers
     int pair_ok = 0, pair_declined = 0;
@@ -129,5 +150,5 @@ int main(int argc, char **argv) {
         if (sfa_plan_batch(qo.data(), 5000, jl, 2, 0, 0, w, slot.data(), &info) != 0) return 7;
     printf("%ld reads, %ld events, %d of 300 corrupt files rejected, %d / %d paired streams inflated / declined, %d quads\n", reads, events, rejected,
            pair_ok, pair_declined, info.n_quads);
-    return (reads > 0 && rejected > 250) ? 0 : 8;
+    return (reads > 0 && rejected > 200) ? 0 : 8;  // (a damaged file whose shard is empty or lies in front of the damage reads clean)
 }
