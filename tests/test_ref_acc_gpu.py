@@ -17,26 +17,34 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver_acc")
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/ref_driver_acc not built (`make -C oracle ref-acc`)")]
 
 
-def _run(k, args, fasta, blow5):
+def _run(k, args, fasta, blow5, raw=False):
     cmd = [DRIVER, "--model", os.path.join(GOLD, "models", f"syn{k}.f32"), "--kmer", str(k), *args, fasta, blow5]
-    r = subprocess.run(cmd, capture_output=True, timeout=600)
+    env = dict(os.environ)
+    env.pop("SIGFISH_ACC_RAW", None)
+    if raw:  # oracle/ref_acc_raw.patch: process_db hands raw samples to sfa_align_raw (events + normalise + align on the GPU)
+        env["SIGFISH_ACC_RAW"] = "1"
+    r = subprocess.run(cmd, capture_output=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return r.stdout.decode()
 
 
+@pytest.mark.parametrize("raw", [False, True], ids=["events_hook", "raw_hook"])
 @pytest.mark.parametrize("name", case_names())
-def test_reference_batch_loop_through_the_hook(name):
+def test_reference_batch_loop_through_the_hook(name, raw):
+    """raw_hook: the same loop with SIGFISH_ACC_RAW=1 -- event detection and normalisation move to the device as well (PAF,
+    -p >= 0; SAM and `-p -1` runs keep the events hook by themselves).  Same bytes either way."""
     c = load_case(name)
-    assert _run(c["k"], [str(a) for a in c["args"]], c["fasta"], c["blow5"]) == c["out_text"]
+    assert _run(c["k"], [str(a) for a in c["args"]], c["fasta"], c["blow5"], raw) == c["out_text"]
 
 
 RANDOM_CASES = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "random", "*.args")))
 
 
+@pytest.mark.parametrize("raw", [False, True], ids=["events_hook", "raw_hook"])
 @pytest.mark.parametrize("name", RANDOM_CASES)
-def test_reference_batch_loop_through_the_hook_random_signals(name):
+def test_reference_batch_loop_through_the_hook_random_signals(name, raw):
     k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
-    got = _run(int(k), args, os.path.join(GOLD, "data", fasta), os.path.join(GOLD, "random", blow5))
+    got = _run(int(k), args, os.path.join(GOLD, "data", fasta), os.path.join(GOLD, "random", blow5), raw)
     assert got == open(os.path.join(GOLD, "random", name + ".out")).read()
 
 
@@ -44,3 +52,5 @@ def test_small_batches_through_the_hook():
     """-K 3: several batches through align_db, context reused between them."""
     c = load_case("rna_sam")
     assert _run(c["k"], [str(a) for a in c["args"]] + ["-K", "3"], c["fasta"], c["blow5"]) == c["out_text"]
+    c = load_case("rna_default")
+    assert _run(c["k"], [str(a) for a in c["args"]] + ["-K", "3"], c["fasta"], c["blow5"], raw=True) == c["out_text"]

@@ -5,7 +5,9 @@
                                              src/dtw_main.c:299-326), on a SAMPLE of the file (the whole file would take the better part
                                              of an hour on 8 threads), scaled by the read count -- per-read cost is constant by construction
   reference+hook oracle/_ref/ref_driver_acc  the same loop, unmodified, with oracle/ref_acc.patch: align_db() calls libsigfish_amd.so
-                                             (what the patch ALONE gives: the reference's serial load / fork-join host stages stay)
+                                             (what the patch ALONE gives: the reference's serial load / fork-join host stages stay);
+                                             and with SIGFISH_ACC_RAW=1 (oracle/ref_acc_raw.patch): event detection + normalisation move
+                                             to the device too (sfa_align_raw), parsing, loading and output stay the reference's
   sigfish-amd    sigfish_amd/bin/sigfish-amd dtw   this repo's command line at the same -K / -t, and at its own defaults
 
 All three at the reference's defaults -K 512 -t 8 (src/sigfish.c:1124-1128); the reference-side runs with --profile-cpu, i.e. its
@@ -35,11 +37,11 @@ def sha(b):
     return hashlib.sha256(b).hexdigest()[:16]
 
 
-def run(cmd, out_path):
+def run(cmd, out_path, env=None):
     time.sleep(1.0)  # the previous process's device contexts are gone (tools/e2e_bench.py: PAUSE_S)
     t0 = time.perf_counter()
     with open(out_path, "wb") as fo:
-        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, env=env)
     dt = time.perf_counter() - t0
     if r.returncode != 0:
         raise RuntimeError(f"{' '.join(cmd)} failed ({r.returncode}): {r.stderr.decode()[-400:]}")
@@ -90,6 +92,13 @@ def main():
         acc_rows = open(os.path.join(d, "acc.paf"), "rb").read()
         n = acc_rows.count(b"\n")
         out["reference_with_hook"] = {"reads": n, "wall_s": round(dt, 3), "stages": stage_timers(err), "reads_per_s": round(n / dt, 1)}
+        # 2b. ... with oracle/ref_acc_raw.patch switched on: event detection and normalisation on the device as well (sfa_align_raw)
+        dt, err = run([os.path.join(REF, "ref_driver_acc"), *ref_args, fasta, files["full"]], os.path.join(d, "accraw.paf"),
+                      env=dict(os.environ, SIGFISH_ACC_RAW="1"))
+        raw_rows = open(os.path.join(d, "accraw.paf"), "rb").read()
+        out["reference_with_raw_hook"] = {"reads": raw_rows.count(b"\n"), "wall_s": round(dt, 3), "stages": stage_timers(err),
+                                          "reads_per_s": round(raw_rows.count(b"\n") / dt, 1), "identical_to_reference_with_hook": raw_rows == acc_rows,
+                                          "note": "stages: `dtw_s` covers events + normalise + align (one call into the library)"}
         # 3. this repo's command line: same -K / -t, then its defaults
         for key, extra in (("sigfish_amd_same_K_t", ["-K", str(a.K), "-t", str(a.t)]), ("sigfish_amd_defaults_t16", ["-t", "16"]),
                            ("sigfish_amd_same_K_t_profile_cpu", ["-K", str(a.K), "-t", str(a.t), "--profile-cpu=yes"])):
