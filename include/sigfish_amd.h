@@ -82,14 +82,14 @@ typedef struct sfa_ctx sfa_ctx_t;
 /* Device-side timing of the last call (HIP events recorded on the stream the kernels run on). */
 typedef struct {
     double fill_ms;        /* pass 1: sdtw_fill_kernel (the dominant kernel).  A batch with queries beyond 2048 events runs their
-                              row strips on a second stream beside the other kernels ("long_overlap"): the stages then overlap,
-                              fill_ms is the device time of the whole batch (= total_ms) and trace_ms is 0 */
+                              row strips on streams of their own beside the other kernels: the stages then overlap, fill_ms is the
+                              device time of the whole batch (= total_ms) and trace_ms is 0 */
     double trace_ms;       /* pass 2: sdtw_trace_kernel (start-column recovery of the winners) */
     double finalize_ms;    /* per-read reductions / row assembly */
     double total_ms;       /* first kernel start -> last kernel end */
     int64_t cells;         /* DP cells of the batch, algorithmic: sum(qlen) * sum over (contig,strand) of rlen */
     int64_t fill_launches; /* fill launches in the call (1) */
-    int64_t ckpt_interval; /* steps between checkpoints (0: none / single pass) */
+    int64_t ckpt_interval; /* steps between the snapshots of pass 1 in HBM (with lds_ckpt: of the sparse store) */
     int64_t ckpt_bytes;    /* HBM taken by the checkpoints of the batch */
     int64_t n_tasks;       /* wave-tasks of the fill launch */
     int64_t n_chunks;      /* pieces the (contig,strand) list was cut into */
@@ -105,8 +105,10 @@ typedef struct {
     double decode_ms;      /* sfa_align_blow5 only: record decompression (inflate), field parsing and signal decoding on the device */
     int64_t blow5_fallbacks; /* batches of this context handed to the host reader because the device declined a record */
     int64_t lds_ckpt;      /* 1: the fill kept its rolling checkpoints in LDS (ckpt_interval is then the sparse HBM store's);
-                              2: and pass 2 ran inside the fill launch (fill_ms covers both, trace_ms is 0) */
+                              2: and pass 2 ran inside the fill launch; 0: every snapshot went to HBM */
     int64_t trace_margin;  /* head start of pass 2 in steps (a whole query + lanes, or less: see "trace_margin") */
+    int64_t fused_trace;   /* 1: pass 2 ran inside the fill launch by ticket (fill_ms covers both, trace_ms is 0) -- the LDS-checkpoint
+                              fill or the 32-row fill */
 } sfa_profile_t;
 
 /* How a batch is laid out on the device (host logic only; needs no GPU). */

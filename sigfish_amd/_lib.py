@@ -26,7 +26,7 @@ class SfaProfile(C.Structure):
                 ("total_ms", C.c_double), ("cells", C.c_int64), ("fill_launches", C.c_int64),
                 ("ckpt_interval", C.c_int64), ("ckpt_bytes", C.c_int64), ("n_tasks", C.c_int64),
                 ("n_chunks", C.c_int64), ("n_segments", C.c_int64), ("segment_reruns", C.c_int64),
-                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64), ("decode_ms", C.c_double), ("blow5_fallbacks", C.c_int64), ("lds_ckpt", C.c_int64), ("trace_margin", C.c_int64)]
+                ("events_ms", C.c_double), ("normalise_ms", C.c_double), ("non_finite_reads", C.c_int64), ("decode_ms", C.c_double), ("blow5_fallbacks", C.c_int64), ("lds_ckpt", C.c_int64), ("trace_margin", C.c_int64), ("fused_trace", C.c_int64)]
 
 
 class SfaPlanInfo(C.Structure):

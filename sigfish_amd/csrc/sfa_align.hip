@@ -328,6 +328,7 @@ int align_sliced(sfa_ctx *c, const float *d_queries, const int64_t *q_off, int32
         sum.ckpt_bytes = std::max(sum.ckpt_bytes, c->prof.ckpt_bytes);
         sum.trace_margin = std::max(sum.trace_margin, c->prof.trace_margin);
         sum.lds_ckpt = std::max(sum.lds_ckpt, c->prof.lds_ckpt);
+        sum.fused_trace = std::max(sum.fused_trace, c->prof.fused_trace);
         sum.n_tasks += c->prof.n_tasks;
         sum.n_chunks = std::max(sum.n_chunks, c->prof.n_chunks);
         sum.non_finite_reads += c->prof.non_finite_reads;
@@ -619,6 +620,7 @@ int sfa::align_device(sfa_ctx *c, const float *d_queries, const int64_t *q_off, 
     c->prof.ckpt_interval = plan.ck_shift ? (1 << plan.ck_shift) : 0;
     c->prof.ckpt_bytes = static_cast<int64_t>(sizeof(float)) * plan.ck_floats;
     c->prof.lds_ckpt = plan.lds_ckpt ? (fused ? 2 : 1) : 0;
+    c->prof.fused_trace = (fused && n_quads > 0) ? 1 : 0;
     c->prof.trace_margin = plan.trace_margin;
     c->prof.n_tasks = da.n_tasks;
     c->prof.n_chunks = n_chunks;
@@ -653,6 +655,7 @@ int sfa::resolve_profile(sfa_ctx *c) {
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     HIP_TRY(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
     HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[4]));
+    if (c->prof.fused_trace) d = 0;  // pass 2 ran inside the fill launch: there was no trace launch to time
     if (c->long_pending) {  // the row-strip sweeps of long queries are fills
         float l = 0;
         HIP_TRY(hipEventElapsedTime(&l, c->ev[5], c->ev[4]));

@@ -328,6 +328,7 @@ int sfa_get_profile(sfa_ctx_t *c, sfa_profile_t *p) {
             sum.n_chunks = std::max(sum.n_chunks, q.n_chunks);
             sum.n_segments = std::max(sum.n_segments, q.n_segments);
             sum.lds_ckpt = std::max(sum.lds_ckpt, q.lds_ckpt);
+            sum.fused_trace = std::max(sum.fused_trace, q.fused_trace);
             sum.trace_margin = std::max(sum.trace_margin, q.trace_margin);
         }
         *p = sum;

@@ -11,7 +11,7 @@
 
 #include "../../include/sigfish_amd.h"
 
-extern "C" void sfa_set_error_(const char *) {}  // defined in sfa_capi.hip, which is not part of this build
+extern "C" void sfa_set_error_(const char *) {}  // defined in sfa_context.hip, which is not part of this build
 
 static std::vector<unsigned char> slurp(const char *p) {
     std::vector<unsigned char> b;

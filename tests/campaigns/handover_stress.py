@@ -87,8 +87,9 @@ def main():
                 for al in (fused, plain):
                     al.set_option("trace_margin", margin)
                 a = fused.align_db(q, q_off)
-                assert fused.profile()["trace_ms"] < 0.05  # (no launch of its own: pass 2 ran inside the fill launch)
+                assert fused.profile()["fused_trace"] == 1  # pass 2 ran inside the fill launch
                 b = plain.align_db(q, q_off)
+                assert plain.profile()["fused_trace"] == 0
                 ok = a.tobytes() == b.tobytes()
                 m = 24
                 want = O.align_batch(q, q_off[:m + 1], oref, flag, threads=16)

@@ -604,8 +604,9 @@ def test_pass_2_head_start_follows_the_previous_batch(oracle):
         assert al.align_db(q, q_off).tobytes() == first.tobytes() and al.profile()["trace_margin"] == 500 + 16
         # the same with pass 2 inside the fill launch: its waves keep the histogram of spans themselves
         al.set_option("trace_margin", -1)
+        assert al.profile()["fused_trace"] == 0  # (300 reads: fewer wave-tasks than wave slots, pass 2 as its own launch)
         al.set_option("fused_trace", 2)
-        assert al.align_db(q, q_off).tobytes() == first.tobytes()
+        assert al.align_db(q, q_off).tobytes() == first.tobytes() and al.profile()["fused_trace"] == 1 and al.profile()["trace_ms"] == 0
         assert al.align_db(q, q_off).tobytes() == first.tobytes() and 500 * 10 // 16 <= al.profile()["trace_margin"] < 500 + 16
 
 
