@@ -391,6 +391,7 @@ __global__ void __launch_bounds__(64) ev_peaks_kernel(const EvArgs a) {
 // sequential kernel; so are very short and very long reads.
 constexpr int kSpecCap = 96;        // emissions a lane can hold (own chunk + catching up)
 constexpr int kSpecMinChunk = 24;   // samples per lane below which speculation is not worth it
+constexpr int kSpecBias = 1024;     // list entries hold (position - chunk start + kSpecBias): peaks up to 1024 samples in front of a chunk
 
 struct Det2 {
     PeakDet32 d[2];
@@ -445,9 +446,11 @@ __device__ __forceinline__ void det2_step(Det2 &D, const EvArgs &a, int n, int j
 
 __global__ void __launch_bounds__(64) ev_peaks_spec_kernel(const EvArgs a) {
     // per lane: the kept peaks in emission order, and for every firing of the short detector its sample, its peak and the
-    // number of list entries before it
-    __shared__ int e_pk[64][kSpecCap];
-    __shared__ int f_j[64][kSpecCap / 2], f_pk[64][kSpecCap / 2], f_at[64][kSpecCap / 2];
+    // number of list entries before it.  Positions are kept RELATIVE to the lane's chunk (+ kSpecBias: a peak may lie a window in
+    // front of it) in 16 bits -- a lane never looks beyond two chunks of at most 3 * kSpecCap samples -- which makes the lists
+    // 30 KB per wave instead of 61: five waves per CU instead of two for a kernel whose lanes chase their own strided loads.
+    __shared__ unsigned short e_pk[64][kSpecCap];
+    __shared__ unsigned short f_j[64][kSpecCap / 2], f_pk[64][kSpecCap / 2], f_at[64][kSpecCap / 2];
     __shared__ int n_own[64], n_fire[64], sync_from[64];
     const int i = blockIdx.x, lane = threadIdx.x;
     const int64_t b = a.raw_off[i];
@@ -459,6 +462,7 @@ __global__ void __launch_bounds__(64) ev_peaks_spec_kernel(const EvArgs a) {
     }
     const float *t1 = a.t1 + b, *t2 = a.t2 + b;
     const int c0 = min(n, lane * C), c1 = min(n, c0 + C);
+    const int rel0 = lane * C - kSpecBias;  // what this lane's list entries are relative to (lane * C, not c0: lane l - 1 derives it too)
     Det2 D;
     D.d[0] = PeakDet32{a.thr1, a.w1, 0, -1, 3.402823466e+38f, false};
     D.d[1] = PeakDet32{a.thr2, a.w2, 0, -1, 3.402823466e+38f, false};
@@ -470,21 +474,23 @@ __global__ void __launch_bounds__(64) ev_peaks_spec_kernel(const EvArgs a) {
         bool sf;
         det2_step(D, a, n, j, t1[j], t2[j], ps, pl, sf, spk);
         if (sf) {
-            if (fires < kSpecCap / 2) {
-                f_j[lane][fires] = j;
-                f_pk[lane][fires] = spk;
-                f_at[lane][fires] = cnt;
+            if (fires < kSpecCap / 2 && spk >= rel0) {
+                f_j[lane][fires] = static_cast<unsigned short>(j - rel0);
+                f_pk[lane][fires] = static_cast<unsigned short>(spk - rel0);
+                f_at[lane][fires] = static_cast<unsigned short>(cnt);
                 ++fires;
             } else {
-                fail = true;
+                fail = true;  // (list full, or a peak further in front of the chunk than the bias: the sequential kernel takes the read)
             }
         }
         if (ps >= 0) {
-            if (cnt < kSpecCap) e_pk[lane][cnt] = ps;
+            if (ps < rel0) fail = true;
+            if (cnt < kSpecCap) e_pk[lane][cnt] = static_cast<unsigned short>(ps - rel0);
             ++cnt;
         }
         if (pl >= 0) {
-            if (cnt < kSpecCap) e_pk[lane][cnt] = pl;
+            if (pl < rel0) fail = true;
+            if (cnt < kSpecCap) e_pk[lane][cnt] = static_cast<unsigned short>(pl - rel0);
             ++cnt;
         }
     }
@@ -499,28 +505,31 @@ __global__ void __launch_bounds__(64) ev_peaks_spec_kernel(const EvArgs a) {
         const int nl = lane + 1;
         const int nf = n_fire[nl];
         const int end = min(n, c1 + C);
+        const int reln = nl * C - kSpecBias;  // lane l + 1's origin
         int m = 0;  // next candidate firing of lane l+1
         bool synced = false;
         for (int j = c1; j < end && !synced; ++j) {
             int ps, pl, spk;
             bool sf;
             det2_step(D, a, n, j, t1[j], t2[j], ps, pl, sf, spk);
-            while (m < nf && f_j[nl][m] < j) ++m;
-            if (sf && m < nf && f_j[nl][m] == j && f_pk[nl][m] == spk) {
+            while (m < nf && static_cast<int>(f_j[nl][m]) + reln < j) ++m;
+            if (sf && m < nf && static_cast<int>(f_j[nl][m]) + reln == j && static_cast<int>(f_pk[nl][m]) + reln == spk) {
                 sync_from[nl] = f_at[nl][m];  // lane l+1's list counts from the entry of this firing on (or the next one kept)
                 synced = true;
                 break;                        // the long detector's turn at this sample belongs to lane l+1's walk
             }
             if (ps >= 0) {
-                if (cnt < kSpecCap) e_pk[lane][cnt] = ps;
+                if (ps < rel0) fail = true;
+                if (cnt < kSpecCap) e_pk[lane][cnt] = static_cast<unsigned short>(ps - rel0);
                 ++cnt;
             }
             if (pl >= 0) {
-                if (cnt < kSpecCap) e_pk[lane][cnt] = pl;
+                if (pl < rel0) fail = true;
+                if (cnt < kSpecCap) e_pk[lane][cnt] = static_cast<unsigned short>(pl - rel0);
                 ++cnt;
             }
         }
-        fail = !synced || cnt > kSpecCap;
+        fail = fail || !synced || cnt > kSpecCap;
     }
     if (__any(fail)) {
         if (lane == 0) a.peak_flag[i] = 1;
@@ -541,8 +550,8 @@ __global__ void __launch_bounds__(64) ev_peaks_spec_kernel(const EvArgs a) {
     int32_t *evs = a.ev_start + eo;  // capacity n + 2 > total + 1
     int w = 1 + incl - mine;         // event e starts at the (e-1)-th peak, event 0 at sample 0
     if (c0 < n)
-        for (int k = from; k < own; ++k) evs[w++] = e_pk[lane][k];
-    for (int k = own; k < cnt; ++k) evs[w++] = e_pk[lane][k];
+        for (int k = from; k < own; ++k) evs[w++] = static_cast<int>(e_pk[lane][k]) + rel0;
+    for (int k = own; k < cnt; ++k) evs[w++] = static_cast<int>(e_pk[lane][k]) + rel0;
     if (lane == 0) {
         evs[0] = 0;
         a.n_events[i] = total ? total + 1 : 0;  // the last event runs to the end of the signal; no peak at all -> no events
