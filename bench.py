@@ -282,7 +282,7 @@ def main():
     if rank != 0:
         al.close()
         dist.destroy_process_group()
-        return
+        return  # (this rank's GPU is free from here on: rank 0's end-to-end leg below starts one process per GPU)
 
     total_reads = job_reads * args.steps
     value = total_reads / elapsed
@@ -396,6 +396,19 @@ def main():
         try:
             out["end_to_end"] = e2e_bench.measure(reads=args.e2e_reads, threads=min(host_cores(), 16))
         except Exception as e:  # the headline line must not depend on scratch space for multi-GB files
+            out["end_to_end"] = {"error": str(e)[:300]}
+    # ... and for N > 1 the same command line as it is meant to run on a node: one process per GPU (`--ranks N --device 0..N-1`),
+    # against one process on one GPU, same file, outputs compared.  The other ranks of this bench have released their GPUs.
+    if world > 1 and not args.no_e2e and args.workload == "ncov_r9_dna_q250":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import e2e_bench
+        try:
+            time.sleep(2.0)  # the other ranks are leaving
+            # this process still holds a context on GPU 0: beyond four GPUs the command line gets the OTHER GPUs, so that no more
+            # processes use the node's GPUs at once than this bench itself did (rank 0 + one per remaining GPU)
+            devs = list(range(world)) if world <= 4 else list(range(1, world))
+            out["end_to_end"] = e2e_bench.measure_sharded(len(devs), devs, threads=min(host_cores(), 16 * len(devs)), reads=4 * args.e2e_reads)
+        except Exception as e:
             out["end_to_end"] = {"error": str(e)[:300]}
     print(json.dumps(out), flush=True)
     if world > 1 or force_dist:

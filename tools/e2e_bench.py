@@ -53,13 +53,15 @@ def _warm(path):
             pass
 
 
-def _run_cli(model, path, threads, k, extra=(), ranks=1):
+def _run_cli(model, path, threads, k, extra=(), ranks=1, devices=None):
     """One timed run of the command line (process start to exit, output to a file); returns (seconds, output path owner's dir
     file, per-rank wall list | None)."""
     paf = os.path.join(os.path.dirname(path), "out.paf")
     cmd = [BIN, "dtw", "--kmer-model", model, "-t", str(threads), "-K", str(k), "-B", "2G", "--verbose", "3" if ranks > 1 else "0", *extra]
     if ranks > 1:
         cmd += ["--ranks", str(ranks)]
+    if devices:
+        cmd += ["--device", ",".join(str(d) for d in devices)]
     cmd += [os.path.join(GOLD, "data", "nCoV-2019.reference.fasta"), path]
     time.sleep(PAUSE_S)
     t0 = time.perf_counter()
@@ -178,6 +180,46 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
     return out
 
 
+def measure_sharded(ranks, devices, threads=16, reads=1_600_000):
+    """The command line over SEVERAL GPUs of one node, one process per GPU (`--ranks G --device d0,d1,...`), against one process on
+    the first of them, on ONE generated compressed file: whole-process reads/s of both, per-rank wall times, and whether the two
+    outputs are the same bytes.  What bench.py adds to its line for --gpus N > 1.  Process start-up (0.3-0.4 s per rank, in
+    parallel) is part of every figure: with `reads` fixed the speed-up is bounded by it, this is a functional check on real
+    multi-GPU hardware first and a scaling figure second."""
+    d, where = _scratch_dir(reads * 4200 * 2)
+    out = {"unit": "reads/s", "ranks": ranks, "devices": list(devices), "host_threads": threads, "files_in": where,
+           "what": f"raw compressed BLOW5 -> PAF through `sigfish-amd dtw --ranks {ranks} --device ...` (one process per GPU, each mapping its "
+                   "byte slice of the file, output gathered in rank order) against one process on one GPU; process start to exit"}
+    try:
+        lv = np.fromfile(os.path.join(GOLD, "models", "syn6.f32"), np.float32)
+        model = os.path.join(d, "syn6.model")
+        with open(model, "w") as f:
+            f.write("#k\t6\nkmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
+            for kmer, v in zip(itertools.product("ACGT", repeat=6), lv):
+                f.write("%s\t%.4f\t1.5000\t1.0\t1.0\n" % ("".join(kmer), v))
+        copies = max(reads // 5, 1)
+        want_head = open(os.path.join(GOLD, "cases", "dna_default.out")).read().splitlines()
+        path = os.path.join(d, "compressed.blow5")
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
+                        "--copies", str(copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True)
+        out["file_MB"] = round(os.path.getsize(path) / 1e6, 1)
+        _warm(path)
+        dt, paf, _ = _run_cli(model, path, min(threads, 16), 4096, devices=[devices[0]])
+        n = _check_rows(paf, copies, want_head, "the one-process run")
+        sha = _sha(paf)
+        out["reads"] = n
+        out["one_process_one_gpu"] = round(n / dt, 1)
+        dt, paf, walls = _run_cli(model, path, threads, 4096, ranks=ranks, devices=devices)
+        n = _check_rows(paf, copies, want_head, f"the run with --ranks {ranks}")
+        out[f"ranks{ranks}"] = round(n / dt, 1)
+        out["rank_wall_s"] = walls
+        out["identical_to_one_process"] = _sha(paf) == sha
+        out["speedup"] = round(out[f"ranks{ranks}"] / out["one_process_one_gpu"], 2)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=400_000)
@@ -185,7 +227,12 @@ if __name__ == "__main__":
     ap.add_argument("--ks", default="4096,512")
     ap.add_argument("--no-long-file", action="store_true", help="skip the run on a file four times as long")
     ap.add_argument("--ranks", default="2", help="comma separated --ranks values for the sharded runs (empty: none)")
+    ap.add_argument("--sharded", default=None, metavar="d0,d1,...", help="instead: measure_sharded() over these devices (one rank per entry)")
     ap.add_argument("extra", nargs="*")
     a = ap.parse_args()
+    if a.sharded:
+        devs = [int(x) for x in a.sharded.split(",")]
+        print(json.dumps(measure_sharded(len(devs), devs, a.threads, a.reads)))
+        sys.exit(0)
     print(json.dumps(measure(a.reads, a.threads, tuple(int(k) for k in a.ks.split(",")), extra=a.extra, long_file=not a.no_long_file,
                              ranks=tuple(int(g) for g in a.ranks.split(",") if g))))
