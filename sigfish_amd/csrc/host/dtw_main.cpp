@@ -111,7 +111,8 @@ void help(FILE *fp, const Opt &o) {
     fprintf(fp, "   --pore STR                 set the pore chemistry (r9, r10 or rna004) [auto]\n");
     fprintf(fp, "   --device INT[,INT...]      GPU(s) to use; batches are dealt to them in turn [0]\n   --host-events              detect events on host threads instead of the GPU\n   --gpu-parse | --host-parse decompress and parse the records on the GPU | on host threads [host threads up to 2 GPUs per process, GPU beyond]\n   --streams INT              device contexts taking batches in turn [2]\n");
     fprintf(fp, "   --ranks INT                read-shard the run over INT processes (rank r: device r of the list, -t/INT threads, the r-th\n"
-                "                              byte slice of the file); output is printed in rank order = file order [one per distinct device]\n"
+                "                              byte slice of the file, which must be a regular file); output is printed in rank order = file\n"
+                "                              order [one per distinct device]\n"
                 "   --shard r/G                map only the records starting in the r-th of G equal byte slices of the file\n"
                 "   --read-range A:B           map only records A..B-1 of the file (B omitted: to the end)\n"
                 "   --no-header                do not print the SAM header (ranks after the first)\n\nadvanced options:\n");
