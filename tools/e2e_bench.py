@@ -29,6 +29,9 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 # back, 0.11-0.14 s after a second's pause; profiles/r03_logs/rejected_cli_async_init_run_ahead_and_fast_exit.log).  The pause is
 # not timed: the figure is the wall time of ONE command, as a user would run it.
 PAUSE_S = 1.0
+# a hung command line must not take the bench line with it (subprocess.run kills the child; its ranks follow: PR_SET_PDEATHSIG)
+CLI_TIMEOUT_S = 300
+MAKE_TIMEOUT_S = 600
 
 
 def _scratch_dir(need_bytes):
@@ -66,7 +69,7 @@ def _run_cli(model, path, threads, k, extra=(), ranks=1, devices=None):
     time.sleep(PAUSE_S)
     t0 = time.perf_counter()
     with open(paf, "wb") as fo:
-        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE)
+        r = subprocess.run(cmd, stdout=fo, stderr=subprocess.PIPE, timeout=CLI_TIMEOUT_S)
     dt = time.perf_counter() - t0
     if r.returncode != 0:
         raise RuntimeError(f"{' '.join(cmd[1:])} failed: {r.stderr.decode()[-500:]}")
@@ -135,7 +138,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
         for kind, flags in (("uncompressed", []), ("compressed", ["--compress"])):
             path = os.path.join(d, kind + ".blow5")
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
-                            "--copies", str(copies), "--jobs", str(min(threads, 16)), *flags], check=True, capture_output=True)
+                            "--copies", str(copies), "--jobs", str(min(threads, 16)), *flags], check=True, capture_output=True, timeout=MAKE_TIMEOUT_S)
             out[kind + "_file_MB"] = round(os.path.getsize(path) / 1e6, 1)
             _warm(path)
             sha = None
@@ -164,7 +167,7 @@ def measure(reads=400_000, threads=16, ks=(4096, 512), keep_dir=None, extra=(), 
         if long_file and where.startswith("/dev/shm") and room > 3 * long_copies * 5 * 4200:  # (memory-backed scratch only: 6.6 GB at the default size)
             path = os.path.join(d, "compressed_long.blow5")
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
-                            "--copies", str(long_copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True)
+                            "--copies", str(long_copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True, timeout=MAKE_TIMEOUT_S)
             _warm(path)
             dt, paf, _ = _run_cli(model, path, threads, 4096, extra)
             rows = _check_rows(paf, long_copies, want_head, "the long compressed file")
@@ -201,7 +204,7 @@ def measure_sharded(ranks, devices, threads=16, reads=1_600_000):
         want_head = open(os.path.join(GOLD, "cases", "dna_default.out")).read().splitlines()
         path = os.path.join(d, "compressed.blow5")
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", "sp1_dna.blow5"), path,
-                        "--copies", str(copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True)
+                        "--copies", str(copies), "--jobs", str(min(threads, 16)), "--compress"], check=True, capture_output=True, timeout=MAKE_TIMEOUT_S)
         out["file_MB"] = round(os.path.getsize(path) / 1e6, 1)
         _warm(path)
         dt, paf, _ = _run_cli(model, path, min(threads, 16), 4096, devices=[devices[0]])
