@@ -56,6 +56,7 @@ struct Opt {
     int shard_r = 0, shard_n = 1;        // --shard r/G: the records starting in the r-th of G equal byte slices of the file
     int64_t range_a = 0, range_b = -1;   // --read-range A:B: records [A, B) by position in the file (B omitted: to the end)
     bool no_header = false;              // --no-header: no SAM header (every rank but the first of a sharded run)
+    int64_t rank_buffer = 256 * 1000 * 1000;  // --rank-buffer: gathered output kept in memory per rank; what exceeds it goes to an unnamed temporary file
     int device_share = 1;                // ranks of a sharded run that were given the same device as this one (a one-GPU rehearsal of --ranks)
     const char *model_file = nullptr;
     const char *pore = nullptr;
@@ -115,7 +116,8 @@ void help(FILE *fp, const Opt &o) {
                 "                              order [one per distinct device]\n"
                 "   --shard r/G                map only the records starting in the r-th of G equal byte slices of the file\n"
                 "   --read-range A:B           map only records A..B-1 of the file (B omitted: to the end)\n"
-                "   --no-header                do not print the SAM header (ranks after the first)\n\nadvanced options:\n");
+                "   --rank-buffer FLOAT[K/M/G] gathered output kept in memory per rank; the rest waits in an unnamed temporary file [%.0fM]\n"
+                "   --no-header                do not print the SAM header (ranks after the first)\n\nadvanced options:\n", o.rank_buffer / 1e6);
     fprintf(fp, "   --kmer-model FILE          nucleotide k-mer model file (required: builtin models are not bundled)\n");
     fprintf(fp, "   --rna                      the dataset is direct RNA\n");
     fprintf(fp, "   -q INT                     the number of events in query signal to align [%d]\n", o.query);
@@ -315,6 +317,9 @@ int supervise_ranks(Opt &o, double t0) {
         pid_t pid = -1;
         int fd = -1;  // read end of the rank's stdout pipe (rank 0: none)
         std::string out;
+        FILE *spill = nullptr;  // output beyond --rank-buffer (tmpfile(): unnamed, gone with the process)
+        int64_t spilled = 0;
+        bool spill_failed = false;
         int status = -1;
         double wall = 0;
         std::thread th;
@@ -354,14 +359,27 @@ int supervise_ranks(Opt &o, double t0) {
         }
     }
     for (int r = 0; r < G; ++r)
-        rk[r].th = std::thread([&rk, r, t0] {
+        rk[r].th = std::thread([&rk, r, t0, cap = o.rank_buffer] {
             Rank &k = rk[r];
             if (k.fd >= 0) {
                 char buf[1 << 16];
                 for (;;) {
                     const ssize_t n = read(k.fd, buf, sizeof buf);
-                    if (n > 0) k.out.append(buf, static_cast<size_t>(n));
-                    else if (n == 0 || errno != EINTR) break;
+                    if (n > 0) {
+                        // (keep reading whatever happens to the spill file: a rank must never block on its pipe)
+                        if (!k.spill && !k.spill_failed && static_cast<int64_t>(k.out.size()) + n > cap) {
+                            k.spill = tmpfile();
+                            k.spill_failed = !k.spill;
+                        }
+                        if (k.spill) {
+                            if (fwrite(buf, 1, static_cast<size_t>(n), k.spill) != static_cast<size_t>(n)) k.spill_failed = true;
+                            k.spilled += n;
+                        } else if (!k.spill_failed) {
+                            k.out.append(buf, static_cast<size_t>(n));
+                        }
+                    } else if (n == 0 || errno != EINTR) {
+                        break;
+                    }
                 }
                 close(k.fd);
             }
@@ -373,13 +391,27 @@ int supervise_ranks(Opt &o, double t0) {
     int rc = EXIT_SUCCESS;
     for (int r = 0; r < G; ++r) {
         rk[r].th.join();
-        const bool ok = WIFEXITED(rk[r].status) && WEXITSTATUS(rk[r].status) == 0;
+        const bool ok = WIFEXITED(rk[r].status) && WEXITSTATUS(rk[r].status) == 0 && !rk[r].spill_failed;
         if (o.verbosity >= 3)
             fprintf(stderr, "[dtw_main] rank %d/%d (device %d, %d host threads): %s after %.3f sec, %zu bytes of output gathered\n", r, G,
-                    o.devices[r % o.devices.size()], threads_each, ok ? "done" : "FAILED", rk[r].wall, rk[r].out.size());
+                    o.devices[r % o.devices.size()], threads_each, ok ? "done" : "FAILED", rk[r].wall, rk[r].out.size() + static_cast<size_t>(rk[r].spilled));
+        if (rk[r].spill_failed) fprintf(stderr, "[sigfish-amd] ERROR: rank %d: the temporary file for output beyond --rank-buffer could not be written\n", r);
         if (!ok) rc = EXIT_FAILURE;
         if (rc == EXIT_SUCCESS && !rk[r].out.empty() && fwrite(rk[r].out.data(), 1, rk[r].out.size(), stdout) != rk[r].out.size()) rc = EXIT_FAILURE;
         std::string().swap(rk[r].out);
+        if (rk[r].spill) {
+            if (rc == EXIT_SUCCESS) {
+                rewind(rk[r].spill);
+                std::vector<char> buf(1 << 20);
+                for (size_t n; (n = fread(buf.data(), 1, buf.size(), rk[r].spill)) > 0;)
+                    if (fwrite(buf.data(), 1, n, stdout) != n) {
+                        rc = EXIT_FAILURE;
+                        break;
+                    }
+                if (ferror(rk[r].spill)) rc = EXIT_FAILURE;
+            }
+            fclose(rk[r].spill);
+        }
     }
     fflush(stdout);
     if (rc != EXIT_SUCCESS) fprintf(stderr, "[sigfish-amd] ERROR: a rank of the sharded run failed; output is incomplete\n");
@@ -427,6 +459,7 @@ static int dtw_run(int argc, char **argv) {
                           {"window", required_argument, 0, 'w'},    {"meth-model", required_argument, 0, 13},   {"host-events", no_argument, 0, 14},   {"streams", required_argument, 0, 15},   {"host-parse", no_argument, 0, 16},   {"gpu-parse", no_argument, 0, 17},   
                           {"ranks", required_argument, 0, 20},      {"shard", required_argument, 0, 21},
                           {"read-range", required_argument, 0, 22}, {"no-header", no_argument, 0, 23},
+                          {"rank-buffer", required_argument, 0, 25},
                           {0, 0, 0, 0}};
     Opt o;
     FILE *fp_help = stderr;
@@ -495,6 +528,7 @@ static int dtw_run(int argc, char **argv) {
                 break;
             }
             case 23: o.no_header = true; break;
+            case 25: o.rank_buffer = parse_num(optarg); if (o.rank_buffer < 0) die("--rank-buffer should not be negative"); break;
             case 15: o.streams = atoi(optarg); if (o.streams < 1 || o.streams > 8) die("--streams should be 1..8"); break;
             default: help(stderr, o); exit(EXIT_FAILURE);
         }

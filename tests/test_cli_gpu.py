@@ -135,7 +135,9 @@ def test_cli_ranks_print_the_single_process_output(name, ranks, models):
 
 @pytest.mark.parametrize("name", RANDOM_CASES)
 @pytest.mark.parametrize("extra", [["--ranks", "2"], ["--ranks", "3", "-K", "7"], ["--ranks", "4", "-K", "3", "--gpu-parse"],
-                                   ["--ranks", "3", "-K", "5", "--host-events"], ["--ranks", "2", "--device", "0,0", "-t", "3"]])
+                                   ["--ranks", "3", "-K", "5", "--host-events"], ["--ranks", "2", "--device", "0,0", "-t", "3"],
+                                   # gathered output beyond --rank-buffer waits in a temporary file: none / a few hundred bytes in memory
+                                   ["--ranks", "3", "--rank-buffer", "0"], ["--ranks", "2", "-K", "6", "--rank-buffer", "300"]])
 def test_cli_ranks_on_random_signal_goldens(name, extra, models):
     """40-read compressed files, ragged batches inside every rank (-K 3/5/7 against 10-20 reads per rank)."""
     k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
@@ -177,6 +179,10 @@ def test_cli_ranks_report_and_failures(models, tmp_path):
     assert r.returncode == 0 and r.stdout.decode() == c["out_text"], r.stderr.decode()
     lines = re.findall(r"\[dtw_main\] rank (\d)/2 \(device 0, 2 host threads\): done after ([0-9.]+) sec, (\d+) bytes of output gathered", r.stderr.decode())
     assert [l[0] for l in lines] == ["0", "1"], r.stderr.decode()
+    spilled = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "3", "--ranks", "2", "--rank-buffer", "100", c["fasta"], c["blow5"]],
+                             capture_output=True, timeout=300)
+    assert spilled.returncode == 0 and spilled.stdout.decode() == c["out_text"], spilled.stderr.decode()
+    assert [l[2] for l in re.findall(r"rank (\d)/2 \(([^)]*)\): done after [0-9.]+ sec, (\d+) bytes", spilled.stderr.decode())] == [l[2] for l in lines]
     for extra, msg in ((["--ranks", "2", "--shard", "0/2"], "cannot be combined"), (["--ranks", "2", "--read-range", "0:3"], "cannot be combined"),
                        (["--shard", "2/2"], "0 <= r < G"), (["--read-range", "5"], "A:B"), (["--ranks", "0"], "1..64"),
                        (["--ranks", "2", "--debug-break", "1"], "--ranks 1")):

@@ -39,7 +39,7 @@ def test_query_size_zero_is_rejected_at_parse_time():
 def test_help_lists_the_switches():
     r = subprocess.run([BIN, "dtw", "-h"], capture_output=True, timeout=60)
     assert r.returncode == 0
-    for word in ("--profile-cpu=yes|no", "--accel=yes|no", "--sam", "--kmer-model", "--ranks", "--shard", "--read-range", "--no-header"):
+    for word in ("--profile-cpu=yes|no", "--accel=yes|no", "--sam", "--kmer-model", "--ranks", "--shard", "--read-range", "--no-header", "--rank-buffer"):
         assert word in r.stdout.decode(), word
 
 
