@@ -328,6 +328,7 @@ int supervise_ranks(Opt &o, double t0) {
     fflush(stdout);
     fflush(stderr);
     const int threads_each = std::max(1, o.threads / G);
+    const pid_t supervisor = getpid();
     for (int r = 0; r < G; ++r) {
         int pfd[2] = {-1, -1};
         if (r > 0 && pipe(pfd) != 0) die("--ranks: cannot create a pipe");
@@ -335,6 +336,7 @@ int supervise_ranks(Opt &o, double t0) {
         if (pid < 0) die("--ranks: cannot start a rank (fork failed)");
         if (pid == 0) {  // the rank
             prctl(PR_SET_PDEATHSIG, SIGTERM);  // a supervisor that dies takes its ranks with it
+            if (getppid() != supervisor) _exit(EXIT_FAILURE);  // (... and one that died before the line above, too)
             for (int q = 1; q < r; ++q) close(rk[q].fd);
             if (r > 0) {
                 close(pfd[0]);
