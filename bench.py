@@ -279,9 +279,13 @@ def main():
         dist.all_reduce(job)
     job_cells, job_bytes, job_reads = (int(v) for v in job.tolist())
 
+    # every rank leaves the process group here, rank 0 included: nothing below is collective, and rank 0's end-to-end leg runs
+    # other processes for minutes -- no communicator should be waiting for peers that have exited meanwhile
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1 or force_dist:
+        dist.destroy_process_group()
     if rank != 0:
         al.close()
-        dist.destroy_process_group()
         return  # (this rank's GPU is free from here on: rank 0's end-to-end leg below starts one process per GPU)
 
     total_reads = job_reads * args.steps
@@ -311,7 +315,7 @@ def main():
         "value": round(value, 1),
         "unit": "reads/s",
         "n_gpus": world,
-        "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+        "rccl_world_size": rccl_world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -411,8 +415,6 @@ def main():
         except Exception as e:
             out["end_to_end"] = {"error": str(e)[:300]}
     print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
