@@ -37,6 +37,9 @@ __global__ void __launch_bounds__(256, 8) k(const float *in, float *out, int ite
             if (MODE == 21) asm volatile("v_sad_u32 %0, %1, %2, %0" : "+v"(a[r]) : "v"(b[r]), "v"(c[r]));  // |b - c| + a, 32-bit unsigned
             // a fixed-point cell in TWO instructions: m = min3(up, diag, left); cell = |x - y| + m
             if (MODE == 22) asm volatile("v_min3_u32 %1, %0, %2, %1\n\tv_sad_u32 %0, %2, %1, %1" : "+v"(a[r]), "+v"(c[r]) : "v"(b[r]));
+            if (MODE == 23) asm volatile("v_minimum3_f32 %0, %0, %1, %2" : "+v"(a[r]) : "v"(b[r]), "v"(c[r]));  // gfx950: IEEE-754-2019 minimum
+            if (MODE == 24) asm volatile("v_sub_f32_e32 %1, %2, %1\n\tv_minimum3_f32 %0, %0, %2, %1\n\tv_add_f32_e64 %0, |%1|, %0" : "+v"(a[r]), "+v"(c[r]) : "v"(b[r]));
+            if (MODE == 25) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(a[r]) : "v"(b[r]), "v"(c[r]));
             if (MODE == 20) asm volatile("v_sub_f32_e32 %1, %2, %1\n\tv_add_f32_e64 %0, |%1|, %0\n\tv_add_f32_e64 %0, |%1|, %0" : "+v"(a[r]), "+v"(c[r]) : "v"(b[r]));
         }
     }
@@ -57,7 +60,7 @@ void run(const char *name, const float *din, float *dout) {
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    const double instr = double(blocks) * 4 * iters * 16 * ((MODE == 11 || MODE == 22) ? 2 : (MODE == 15 || MODE == 20) ? 3 : 1);
+    const double instr = double(blocks) * 4 * iters * 16 * ((MODE == 11 || MODE == 22) ? 2 : (MODE == 15 || MODE == 20 || MODE == 24) ? 3 : 1);
     printf("%-34s %.2f ms  %.3e wave-instr/s  -> %.2f cycles/instr/SIMD @2.4GHz\n", name, ms, instr / (ms * 1e-3), 2.4e9 * 1024 / (instr / (ms * 1e-3)));
 }
 int main() {
@@ -89,5 +92,9 @@ int main() {
     run<20>("sub+add+add (3 instr, no min)", din, dout);
     run<21>("v_sad_u32 (|a-b|+c, VOP3)", din, dout);
     run<22>("min3_u32 + sad_u32 (2 instr, fixed-point cell)", din, dout);
+    run<23>("v_minimum3_f32 (gfx950)", din, dout);
+    run<24>("sub+minimum3+add (3 instr)", din, dout);
+    run<25>("v_pk_minimum3_f16 (gfx950)", din, dout);
+    run<15>("sub+min3+add (3 instr, cell mix) again", din, dout);
     return 0;
 }
