@@ -351,7 +351,9 @@ int32_t sfa_r2qevent_map(const sfa_result_t *r, const sfa_event_t *events, int64
  * in sfa_last_error() after a successful return (empty string: none). */
 int sfa_read_kmer_model(const char *path, float *levels, uint32_t *k);
 
-/* Sequential BLOW5 reader (zlib / svb-zd / uncompressed), the subset of slow5lib the path uses. */
+/* Sequential S/BLOW5 reader, the subset of slow5lib the path uses (slow5_open, src/sigfish.c:110): BLOW5 (zlib / svb-zd /
+ * uncompressed) and its text twin SLOW5 ASCII, told apart by content (slow5lib: by the extension).  Numbers in a text file are
+ * accepted as slow5lib accepts them (slow5_misc.c:103-156); auxiliary columns are counted, not interpreted. */
 typedef struct sfa_blow5 sfa_blow5_t;
 sfa_blow5_t *sfa_blow5_open(const char *path);            /* NULL on failure, see sfa_last_error() */
 const char *sfa_blow5_attr(sfa_blow5_t *f, const char *key); /* header attribute of read group 0 or NULL */

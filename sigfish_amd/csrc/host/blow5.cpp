@@ -11,6 +11,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace sfa {
@@ -18,6 +21,10 @@ namespace sfa {
 namespace {
 const unsigned char kMagic[6] = {'B', 'L', 'O', 'W', '5', 1};
 const unsigned char kEof[5] = {'5', 'W', 'O', 'L', 'B'};
+const char kAsciiFirst[] = "#slow5_version\t";
+const char kAsciiGroups[] = "#num_read_groups\t";
+const char kAsciiTypes[] = "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*";
+const char kAsciiNames[] = "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal";
 
 template <typename T>
 bool take(const uint8_t *&p, const uint8_t *end, T *out) {
@@ -204,8 +211,13 @@ bool Blow5Reader::open(const std::string &path) {
         err_ = "cannot open " + path;
         return false;
     }
+    ascii_ = false;
+    n_aux_ = 0;
+    eof_bytes_ = sizeof kEof;
     unsigned char head[68];
-    if (fread(head, 1, sizeof head, fp_) != sizeof head || memcmp(head, kMagic, sizeof kMagic) != 0) {
+    const size_t got_head = fread(head, 1, sizeof head, fp_);
+    if (got_head >= sizeof kAsciiFirst - 1 && memcmp(head, kAsciiFirst, sizeof kAsciiFirst - 1) == 0) return open_ascii(path);
+    if (got_head != sizeof head || memcmp(head, kMagic, sizeof kMagic) != 0) {
         err_ = path + ": not a BLOW5 file (bad magic number)";
         return false;
     }
@@ -266,6 +278,207 @@ bool Blow5Reader::open(const std::string &path) {
     return true;
 }
 
+// ---- SLOW5 ASCII ------------------------------------------------------------------------------------------------------------
+namespace {
+// slow5_uint_check + strtoull (slow5_misc.c:103-120, 161-186): digits only, no leading zero on a longer number
+bool ascii_uint(const char *p, size_t n, uint64_t max, uint64_t *out) {
+    if (n == 0 || n > 20 || (n > 1 && p[0] == '0')) return false;
+    unsigned __int128 v = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (p[i] < '0' || p[i] > '9') return false;
+        v = v * 10 + static_cast<unsigned>(p[i] - '0');
+    }
+    if (v > max) return false;
+    *out = static_cast<uint64_t>(v);
+    return true;
+}
+// slow5_strtod_check (slow5_misc.c:141-156, 360-376): digits, '.' and '-' only (no exponent), then strtod
+bool ascii_double(const char *p, size_t n, double *out) {
+    if (n == 0 || n >= 400) return false;
+    char buf[400];
+    for (size_t i = 0; i < n; ++i) {
+        if (!((p[i] >= '0' && p[i] <= '9') || p[i] == '.' || p[i] == '-')) return false;
+        buf[i] = p[i];
+    }
+    buf[n] = '\0';
+    errno = 0;
+    *out = strtod(buf, nullptr);
+    return !(errno == ERANGE && (*out == HUGE_VAL || *out == -HUGE_VAL || *out == 0.0));
+}
+// slow5_ato_int16 (slow5_misc.c:122-139, 303-319): digits and '-' only, no leading zero on a longer token, strtol's value in range
+bool ascii_int16(const char *p, size_t n, int16_t *out) {
+    if (n == 0 || (n > 1 && p[0] == '0')) return false;
+    size_t i = p[0] == '-' ? 1 : 0;
+    long v = 0;
+    bool plain = i < n && n - i <= 6;  // the common case: [-]digits
+    for (size_t j = i; plain && j < n; ++j) {
+        if (p[j] < '0' || p[j] > '9') plain = false;
+        else v = v * 10 + (p[j] - '0');
+    }
+    if (!plain) {  // a '-' somewhere else, or a very long token: what strtol makes of it is what the reference takes
+        if (n >= 64) return false;
+        char buf[64];
+        for (size_t j = 0; j < n; ++j) {
+            if (!((p[j] >= '0' && p[j] <= '9') || p[j] == '-')) return false;
+            buf[j] = p[j];
+        }
+        buf[n] = '\0';
+        v = strtol(buf, nullptr, 10);
+    } else if (i) {
+        v = -v;
+    }
+    if (v > INT16_MAX || v < INT16_MIN) return false;
+    *out = static_cast<int16_t>(v);
+    return true;
+}
+}  // namespace
+
+bool parse_slow5_line(const uint8_t *mem, size_t size, uint32_t n_aux, Blow5Record *rec, std::string *err) {
+    rec->record_bytes = size;  // (the reference's -B accounting: the line without its newline, slow5.c:3214)
+    const char *p = reinterpret_cast<const char *>(mem), *const end = p + size;
+    const char *col[8];
+    size_t len[8];
+    int n_col = 0;
+    while (n_col < 8) {
+        const char *tab = static_cast<const char *>(memchr(p, '\t', static_cast<size_t>(end - p)));
+        col[n_col] = p;
+        len[n_col] = static_cast<size_t>((tab ? tab : end) - p);
+        ++n_col;
+        if (!tab) {
+            p = nullptr;
+            break;
+        }
+        p = tab + 1;
+    }
+    const auto bad = [&](const char *what) {
+        *err = std::string("malformed SLOW5 record (") + what + (n_col > 0 ? ", read " + std::string(col[0], std::min<size_t>(len[0], 64)) : std::string()) + ")";
+        return false;
+    };
+    if (n_col < 8) return bad("fewer than the eight primary columns");
+    rec->read_id.assign(col[0], len[0]);
+    uint64_t group = 0, n = 0;
+    if (!ascii_uint(col[1], len[1], UINT32_MAX, &group)) return bad("read group");
+    rec->read_group = static_cast<uint32_t>(group);
+    if (!ascii_double(col[2], len[2], &rec->digitisation)) return bad("digitisation");
+    if (!ascii_double(col[3], len[3], &rec->offset)) return bad("offset");
+    if (!ascii_double(col[4], len[4], &rec->range)) return bad("range");
+    if (!ascii_double(col[5], len[5], &rec->sampling_rate)) return bad("sampling rate");
+    if (!ascii_uint(col[6], len[6], UINT64_MAX, &n)) return bad("raw signal length");
+    if (n > len[7]) return bad("raw signal length exceeds the record");  // (every sample takes a character at least)
+    rec->raw.resize(n);
+    if (n > 0) {  // (a zero length leaves the signal column unread, slow5.c:2722-2725)
+        const char *q = col[7], *const qend = q + len[7];
+        uint64_t j = 0;
+        for (;;) {
+            const char *comma = static_cast<const char *>(memchr(q, ',', static_cast<size_t>(qend - q)));
+            const char *tend = comma ? comma : qend;
+            if (j >= n) return bad("more samples than the raw signal length");
+            if (!ascii_int16(q, static_cast<size_t>(tend - q), &rec->raw[j])) return bad("raw signal");
+            ++j;
+            if (!comma) break;
+            q = comma + 1;
+        }
+        if (j != n) return bad("fewer samples than the raw signal length");
+    }
+    // auxiliary columns: present in the record exactly when the header announced them (slow5.c:2778-2800); counted, not read
+    uint32_t more = 0;
+    for (; p; ++more) {
+        const char *tab = static_cast<const char *>(memchr(p, '\t', static_cast<size_t>(end - p)));
+        p = tab ? tab + 1 : nullptr;
+    }
+    if (more != n_aux) return bad(more < n_aux ? "auxiliary fields missing" : "auxiliary fields the header does not announce");
+    return true;
+}
+
+bool Blow5Reader::open_ascii(const std::string &path) {
+    ascii_ = true;
+    eof_bytes_ = 0;
+    record_press_ = signal_press_ = 0;
+    rewind(fp_);
+    {
+        struct stat fsb;
+        file_size_ = (fstat(fileno(fp_), &fsb) == 0 && S_ISREG(fsb.st_mode)) ? static_cast<uint64_t>(fsb.st_size) : UINT64_MAX;
+    }
+    char *line = nullptr;
+    size_t cap = 0;
+    uint64_t at = 0;
+    const auto fail = [&](const std::string &what) {
+        free(line);
+        err_ = path + ": malformed SLOW5 header (" + what + ")";
+        return false;
+    };
+    // every header line ends with a newline; returns the length without it, -1 at the end of the file
+    const auto next_line = [&]() -> ssize_t {
+        const ssize_t got = getline(&line, &cap, fp_);
+        if (got <= 0 || line[got - 1] != '\n') return -1;
+        at += static_cast<uint64_t>(got);
+        line[got - 1] = '\0';
+        return got - 1;
+    };
+    ssize_t n = next_line();
+    unsigned ver[3];
+    {  // "#slow5_version\tM.m.p", three uint8 (slow5.c:677-742); files newer than 1.0.0 are refused (slow5_defs.h: SLOW5_VERSION_ARRAY)
+        if (n < 0 || strncmp(line, kAsciiFirst, sizeof kAsciiFirst - 1) != 0) return fail("no slow5_version line");
+        const char *q = line + sizeof kAsciiFirst - 1;
+        for (int k = 0; k < 3; ++k) {
+            const char *dot = k < 2 ? strchr(q, '.') : q + strlen(q);
+            uint64_t v;
+            if (!dot || !ascii_uint(q, static_cast<size_t>(dot - q), 255, &v)) return fail("bad file version");
+            ver[k] = static_cast<unsigned>(v);
+            q = dot + 1;
+        }
+        if (ver[0] > 1 || (ver[0] == 1 && (ver[1] > 0 || ver[2] > 0))) return fail("file version newer than 1.0.0");
+    }
+    n = next_line();
+    {
+        uint64_t g;
+        if (n < 0 || strncmp(line, kAsciiGroups, sizeof kAsciiGroups - 1) != 0) return fail("no num_read_groups line");
+        const char *q = line + sizeof kAsciiGroups - 1;
+        const char *tab = strchr(q, '\t');
+        if (!ascii_uint(q, tab ? static_cast<size_t>(tab - q) : strlen(q), UINT32_MAX, &g) || g == 0) return fail("invalid number of read groups");
+        n_groups_ = static_cast<uint32_t>(g);
+    }
+    // "@attr\tv0[\tv1...]" until the column types (slow5.c:1701-1760): the first value is read group 0's
+    for (;;) {
+        n = next_line();
+        if (n < 0) return fail("no column types line");
+        if (strncmp(line, kAsciiTypes, sizeof kAsciiTypes - 1) == 0) break;
+        if (line[0] != '@') return fail("a line that is neither an attribute nor the column types");
+        const char *tab = strchr(line, '\t');
+        if (!tab) return fail("an attribute without a value");
+        const char *vend = strchr(tab + 1, '\t');
+        attrs_[std::string(line + 1, static_cast<size_t>(tab - line - 1))] = vend ? std::string(tab + 1, static_cast<size_t>(vend - tab - 1)) : std::string(tab + 1);
+    }
+    const auto extra_columns = [](const char *rest, uint32_t *count) {  // "" or "\tname[\tname...]"
+        *count = 0;
+        if (*rest == '\0') return true;
+        if (*rest != '\t') return false;
+        for (const char *q = rest; q; q = strchr(q + 1, '\t')) ++*count;
+        return true;
+    };
+    uint32_t n_types = 0, n_names = 0;
+    if (!extra_columns(line + sizeof kAsciiTypes - 1, &n_types)) return fail("column types");
+    n = next_line();
+    if (n < 0 || strncmp(line, kAsciiNames, sizeof kAsciiNames - 1) != 0 || !extra_columns(line + sizeof kAsciiNames - 1, &n_names))
+        return fail("column names");
+    if (n_types != n_names) return fail("as many auxiliary types as names expected");
+    n_aux_ = n_types;
+    free(line);
+    data_begin_ = pos_ = at;
+    limit_pos_ = limit_records_ = UINT64_MAX;
+    struct stat sb;
+    if (fstat(fileno(fp_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+        void *m = mmap(nullptr, static_cast<size_t>(sb.st_size), PROT_READ, MAP_PRIVATE, fileno(fp_), 0);
+        if (m != MAP_FAILED) {
+            map_ = static_cast<const uint8_t *>(m);
+            map_size_ = static_cast<size_t>(sb.st_size);
+            map_pos_ = static_cast<size_t>(at);
+            madvise(m, map_size_, MADV_SEQUENTIAL);
+        }
+    }
+    return true;
+}
+
 int Blow5Reader::skip_one() {
     if (map_) {
         const uint8_t *m;
@@ -273,6 +486,7 @@ int Blow5Reader::skip_one() {
         return next_view(&m, &n);
     }
     if (!fp_) return -1;
+    if (ascii_) return next_mem(&buf_);
     uint64_t size = 0;
     const size_t got = fread(&size, 1, sizeof size, fp_);
     if (got != sizeof size) {
@@ -303,11 +517,11 @@ bool Blow5Reader::select_shard(uint32_t r, uint32_t G) {
         err_ = "shard index out of range";
         return false;
     }
-    if (file_size_ == UINT64_MAX || file_size_ < data_begin_ + sizeof kEof) {
+    if (file_size_ == UINT64_MAX || file_size_ < data_begin_ + eof_bytes_) {
         err_ = "sharding by byte ranges needs a regular, complete BLOW5 file";
         return false;
     }
-    const uint64_t region = file_size_ - sizeof kEof - data_begin_;
+    const uint64_t region = file_size_ - eof_bytes_ - data_begin_;
     const auto cut = [&](uint32_t k) { return data_begin_ + static_cast<uint64_t>(static_cast<unsigned __int128>(region) * k / G); };
     const uint64_t lo = cut(r);
     while (pos_ < lo) {
@@ -322,6 +536,21 @@ bool Blow5Reader::select_shard(uint32_t r, uint32_t G) {
 int Blow5Reader::next_view(const uint8_t **mem, size_t *size) {
     if (!map_) return -2;  // caller falls back to next_mem()
     if (limit_records_ == 0 || pos_ >= limit_pos_) return 0;
+    if (ascii_) {  // a record is a line (getline in slow5_get_next_mem, slow5.c:3200-3216); the file simply ends
+        if (map_pos_ >= map_size_) return 0;
+        const void *nl = memchr(map_ + map_pos_, '\n', map_size_ - map_pos_);
+        if (!nl) {  // (slow5lib would drop the last character of such a line and carry on)
+            err_ = "malformed SLOW5: the last record does not end with a newline (truncated file?)";
+            return -1;
+        }
+        *mem = map_ + map_pos_;
+        *size = static_cast<size_t>(static_cast<const uint8_t *>(nl) - *mem);
+        map_pos_ += *size + 1;
+        pos_ = map_pos_;
+        if (limit_records_ != UINT64_MAX) --limit_records_;
+        consumed_.store(map_pos_, std::memory_order_relaxed);
+        return 1;
+    }
     if (map_pos_ + sizeof kEof <= map_size_ && map_size_ - map_pos_ == sizeof kEof && memcmp(map_ + map_pos_, kEof, sizeof kEof) == 0) return 0;
     if (map_pos_ + 8 > map_size_) {
         err_ = "malformed BLOW5: missing end-of-file marker";
@@ -345,6 +574,27 @@ int Blow5Reader::next_view(const uint8_t **mem, size_t *size) {
 int Blow5Reader::next_mem(std::vector<uint8_t> *mem) {
     if (!fp_) return -1;
     if (limit_records_ == 0 || pos_ >= limit_pos_) return 0;
+    if (ascii_) {
+        char *line = nullptr;
+        size_t cap = 0;
+        const ssize_t got = getline(&line, &cap, fp_);
+        if (got <= 0) {
+            free(line);
+            if (feof(fp_)) return 0;
+            err_ = "reading the next SLOW5 record failed";
+            return -1;
+        }
+        if (line[got - 1] != '\n') {
+            free(line);
+            err_ = "malformed SLOW5: the last record does not end with a newline (truncated file?)";
+            return -1;
+        }
+        mem->assign(reinterpret_cast<const uint8_t *>(line), reinterpret_cast<const uint8_t *>(line) + got - 1);
+        free(line);
+        pos_ += static_cast<uint64_t>(got);
+        if (limit_records_ != UINT64_MAX) --limit_records_;
+        return 1;
+    }
     uint64_t size = 0;
     const size_t got = fread(&size, 1, sizeof size, fp_);
     if (got != sizeof size) {
@@ -371,6 +621,7 @@ bool Blow5Reader::parse(const std::vector<uint8_t> &mem, Blow5Record *rec, std::
 }
 
 bool Blow5Reader::parse(const uint8_t *mem, size_t size, Blow5Record *rec, std::string *err) const {
+    if (ascii_) return parse_slow5_line(mem, size, n_aux_, rec, err);
     return parse_blow5_record(mem, size, record_press_ == 1, signal_press_ == 1, rec, err);
 }
 
@@ -447,6 +698,10 @@ bool parse_payload(const uint8_t *p, const uint8_t *end, int signal_svb, Blow5Re
 }  // namespace
 
 void Blow5Reader::parse_pair(const uint8_t *const mem[2], const size_t size[2], Blow5Record *const rec[2], std::string *const err[2], bool ok[2]) const {
+    if (ascii_) {
+        for (int k = 0; k < 2; ++k) ok[k] = parse_slow5_line(mem[k], size[k], n_aux_, rec[k], err[k]);
+        return;
+    }
     parse_blow5_record_pair(mem, size, record_press_ == 1, signal_press_ == 1, rec, err, ok);
 }
 

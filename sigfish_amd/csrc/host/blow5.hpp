@@ -9,6 +9,13 @@
 //   u16 id_len, id, u32 read_group, f64 digitisation, f64 offset, f64 range, f64 sampling_rate, u64 len,
 //   signal bytes, auxiliary fields (ignored here).  With signal_press == svb-zd, `len` is the compressed byte
 //   count and the signal is u32 n + StreamVByte(keys ceil(n/4) B, data 1-4 B little endian) of zig-zag deltas.
+//
+// ... and its text twin, SLOW5 ASCII (slow5_open takes either, by the file's extension: slow5lib/src/slow5.c:4219-4229; here
+// by content).  Layout (slow5.c:661-790 header, 1701-1990 attribute / type / name lines, 3200-3216 + 2643-2790 records):
+//   "#slow5_version\tM.m.p" | "#num_read_groups\tN" | "@attr\tv0[\tv1..]" lines | "#char*\tuint32_t\tdouble\tdouble\tdouble\t
+//   double\tuint64_t\tint16_t*[\taux types]" | "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\t
+//   len_raw_signal\traw_signal[\taux names]" | one line per record: the eight primary columns, tab separated, the signal as
+//   comma separated integers, then the auxiliary columns (counted, not interpreted).  No compression, no end-of-file marker.
 #pragma once
 #include <atomic>
 #include <cstdint>
@@ -31,6 +38,10 @@ struct Blow5Record {
 // One record's bytes -> fields + samples, given the file's compression methods (what Blow5Reader::parse does; free-standing
 // for callers that hold record bytes without a reader, e.g. the fallback of the device-side decoder)
 bool parse_blow5_record(const uint8_t *mem, size_t size, int record_zlib, int signal_svb, Blow5Record *rec, std::string *err);
+// One line of a SLOW5 ASCII file (without its newline) -> fields + samples, with slow5lib's acceptance rules for the numbers
+// (slow5_misc.c:103-156: no signs or leading zeros on the unsigned columns, digits '.' '-' only in the doubles);
+// `n_aux`: auxiliary columns the header announced -- the line must carry exactly that many more
+bool parse_slow5_line(const uint8_t *mem, size_t size, uint32_t n_aux, Blow5Record *rec, std::string *err);
 // ... and two of them by one thread, their zlib streams inflated side by side (same results, record by record)
 void parse_blow5_record_pair(const uint8_t *const mem[2], const size_t size[2], int record_zlib, int signal_svb, Blow5Record *const rec[2],
                              std::string *const err[2], bool ok[2]);
@@ -55,6 +66,7 @@ class Blow5Reader {
     const char *attr(const std::string &key) const;
     uint32_t num_read_groups() const { return n_groups_; }
     bool mapped() const { return map_ != nullptr; }           // next_view() works (regular file, mmap succeeded)
+    bool ascii() const { return ascii_; }                     // SLOW5 ASCII: records are lines (host parsing only)
     bool records_zlib() const { return record_press_ == 1; }  // the whole record is a zlib stream
     bool signal_svb() const { return signal_press_ == 1; }    // the signal is StreamVByte of zig-zag deltas
     const std::string &error() const { return err_; }
@@ -74,6 +86,10 @@ class Blow5Reader {
 
   private:
     void stop_prefault();
+    bool open_ascii(const std::string &path);
+    bool ascii_ = false;
+    uint32_t n_aux_ = 0;                   // auxiliary columns of an ASCII file
+    size_t eof_bytes_ = 5;                 // the end-of-file marker behind the records (none in ASCII)
     int skip_one();                        // 1: a record skipped, 0: end of file, -1: error
     uint64_t data_begin_ = 0;              // offset of the first record's size prefix
     uint64_t pos_ = 0;                     // offset of the next record's size prefix (both iterators keep it)

@@ -103,7 +103,7 @@ int64_t parse_num(const char *s) {  // K/M/G suffixes as src/dtw_main.c:46-58
 }
 
 void help(FILE *fp, const Opt &o) {
-    fprintf(fp, "Usage: sigfish-amd dtw [OPTIONS] genome.fa reads.blow5\n\nbasic options:\n");
+    fprintf(fp, "Usage: sigfish-amd dtw [OPTIONS] genome.fa reads.blow5|reads.slow5\n\nbasic options:\n");
     fprintf(fp, "   -t INT                     number of host threads for parsing and event detection [%d]\n", o.threads);
     fprintf(fp, "   -K INT                     batch size (max number of reads loaded at once) [%d]\n", o.batch_size);
     fprintf(fp, "   -B FLOAT[K/M/G]            max number of bytes loaded at once [%.1fM]\n", o.batch_bytes / 1e6);
@@ -720,7 +720,9 @@ static int dtw_run(int argc, char **argv) {
     // file -- 16 cores inflate 0.75 M records/s, the device 1.0 M/s but in competition with the alignment kernels for the same
     // LDS -- and the host route is the better one at the default -K 4096.  What the device route buys is independence from the
     // host: a node's cores do not grow with its GPUs, so it is the default from three devices on.
-    const bool gpu_parse = gpu_events && (o.gpu_parse < 0 ? o.devices.size() > 2 : o.gpu_parse == 1);
+    // (the device route decodes BLOW5 records; the lines of a SLOW5 ASCII file are parsed by the host threads)
+    if (reader.ascii() && o.gpu_parse == 1) die("--gpu-parse decodes BLOW5 records: a SLOW5 ASCII file is parsed on the host threads");
+    const bool gpu_parse = gpu_events && !reader.ascii() && (o.gpu_parse < 0 ? o.devices.size() > 2 : o.gpu_parse == 1);
     const bool sam = (o.flag & F_SAM) != 0;
     const int n_slots = n_ctx + 2;  // one being filled, one per GPU stage in flight, one being printed
     std::vector<Slot> slots(n_slots);

@@ -1,7 +1,8 @@
 // host_asan.cpp -- the host-side units under AddressSanitizer / UBSan (CPU only; the GPU pool forbids GPU sanitizers):
-// BLOW5 reader incl. the own inflate and the SSSE3 StreamVByte decoder, event detection, query selection incl. the RNA
+// BLOW5 / SLOW5 ASCII reader incl. the own inflate and the SSSE3 StreamVByte decoder, event detection, query selection incl. the RNA
 // adaptor / poly-A search, corrupted files, planner.  Built and run by tests/test_c_host.py.
 //   usage: host_asan <scratch dir> <blow5>...
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -107,6 +108,74 @@ int main(int argc, char **argv) {
             }
             if (got != whole || whole == 0) return 14;
         }
+    // SLOW5 ASCII, the text twin: the first file's records written out as text, read back, then damaged 400 times (bytes
+    // replaced by separators, digits, signs and noise; truncation; lines glued together), whole and as shards / ranges
+    int text_rejected = 0;
+    {
+        const std::string text_path = std::string(argv[1]) + "/fz.slow5";
+        std::string text = "#slow5_version\t0.2.0\n#num_read_groups\t1\n@experiment_type\tgenomic_dna\n"
+                           "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\tuint8_t\n"
+                           "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\tflag\n";
+        long written = 0, samples = 0;
+        {
+            sfa_blow5_t *f = sfa_blow5_open(argv[2]);
+            if (!f) return 15;
+            const char *id;
+            double meta[4];
+            const int16_t *raw;
+            int64_t n;
+            char num[64];
+            while (sfa_blow5_next(f, &id, meta, &raw, &n) == 1) {
+                text += std::string(id) + "\t0";
+                for (int k = 0; k < 4; ++k) {
+                    snprintf(num, sizeof num, "\t%.10f", meta[k]);
+                    text += num;
+                }
+                text += "\t" + std::to_string(n) + "\t";
+                for (int64_t i = 0; i < n; ++i) text += (i ? "," : "") + std::to_string(raw[i]);
+                text += "\t1\n";
+                ++written;
+                samples += n;
+            }
+            sfa_blow5_close(f);
+        }
+        const auto read_all = [&](const std::string &body, int mode, long *got, long *got_samples) {
+            FILE *o = fopen(text_path.c_str(), "wb");
+            if (!o) return -2;
+            fwrite(body.data(), 1, body.size(), o);
+            fclose(o);
+            sfa_blow5_t *f = sfa_blow5_open(text_path.c_str());
+            if (!f) return -1;
+            if (mode == 1) (void)sfa_blow5_select_shard(f, static_cast<int32_t>(rng() % 3), 3);
+            if (mode == 2) (void)sfa_blow5_select_records(f, static_cast<int64_t>(rng() % 4), (rng() & 1) ? -1 : static_cast<int64_t>(rng() % 3));
+            const char *id;
+            double meta[4];
+            const int16_t *raw;
+            int64_t n;
+            int rc;
+            while ((rc = sfa_blow5_next(f, &id, meta, &raw, &n)) == 1) {
+                ++*got;
+                for (int64_t i = 0; i < n; ++i) *got_samples += raw[i] != INT16_MIN;  // (touch every sample)
+            }
+            sfa_blow5_close(f);
+            return rc;
+        };
+        long got = 0, got_samples = 0;
+        if (read_all(text, 0, &got, &got_samples) != 0 || got != written || got_samples != samples || written == 0) return 16;
+        static const char kNoise[] = "\t\t,,\n\n--..0123456789ex#@ \0";
+        for (int it = 0; it < 400; ++it) {
+            std::string b = text;
+            switch (it % 4) {
+                case 0: for (int k = 0; k < 3; ++k) b[rng() % b.size()] = kNoise[rng() % (sizeof kNoise - 1)]; break;
+                case 1: b.resize(rng() % b.size()); break;
+                case 2: b.erase(rng() % b.size(), 1 + rng() % 40); break;
+                default: b.insert(rng() % b.size(), std::string(1 + rng() % 5, kNoise[rng() % (sizeof kNoise - 1)])); break;
+            }
+            long g = 0, gs = 0;
+            if (read_all(b, it % 3, &g, &gs) < 0) ++text_rejected;
+        }
+        if (text_rejected < 150) return 17;
+    }
     // the reader's threads inflate records two at a time (sfa_inflate_zlib_pair): pairs of the file's own records, one or both
     // damaged (flipped bits, truncation, random tails), into generous and into too-small buffers
     int pair_ok = 0, pair_declined = 0;
@@ -148,7 +217,7 @@ int main(int argc, char **argv) {
     sfa_plan_info_t info;
     for (int w : {0, 1, 2, 4})
         if (sfa_plan_batch(qo.data(), 5000, jl, 2, 0, 0, w, slot.data(), &info) != 0) return 7;
-    printf("%ld reads, %ld events, %d of 300 corrupt files rejected, %d / %d paired streams inflated / declined, %d quads\n", reads, events, rejected,
-           pair_ok, pair_declined, info.n_quads);
+    printf("%ld reads, %ld events, %d of 300 corrupt files rejected, %d of 400 corrupt text files, %d / %d paired streams inflated / declined, %d quads\n",
+           reads, events, rejected, text_rejected, pair_ok, pair_declined, info.n_quads);
     return (reads > 0 && rejected > 200) ? 0 : 8;  // (a damaged file whose shard is empty or lies in front of the damage reads clean)
 }

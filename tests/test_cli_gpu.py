@@ -41,6 +41,48 @@ def test_cli_matches_reference_output(name, models):
     assert r.stdout.decode() == c["out_text"]
 
 
+@pytest.fixture(scope="module")
+def text_files(tmp_path_factory):
+    """the two fixtures of the reference as SLOW5 ASCII (same reads, same ids; the RNA one with two auxiliary columns)"""
+    import sys
+    d = tmp_path_factory.mktemp("slow5")
+    out = {}
+    for name, aux in (("sp1_dna", 0), ("sequin_rna", 2)):
+        out[name + ".blow5"] = str(d / (name + ".slow5"))
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", name + ".blow5"), out[name + ".blow5"],
+                        "--copies", "1", "--ascii", "--keep-ids", "--aux", str(aux)], check=True, capture_output=True)
+    return out
+
+
+@pytest.mark.parametrize("extra", [[], ["--host-events"], ["--ranks", "2"], ["--ranks", "3", "-K", "2"]])
+@pytest.mark.parametrize("name", case_names())
+def test_cli_reads_slow5_ascii(name, extra, models, text_files):
+    """The text twin of the format (slow5_open takes either): the same reads from a .slow5 file print the reference's output,
+    one process or read-sharded (a rank's part of a text file = the lines starting in its byte slice)."""
+    c = load_case(name)
+    if os.path.basename(c["blow5"]) not in text_files:
+        pytest.skip("case on another input file")
+    args = [str(a) for a in c["args"]]
+    cmd = [BIN, "dtw", "--kmer-model", models[c["k"]], "--verbose", "0", *extra, *args, c["fasta"], text_files[os.path.basename(c["blow5"])]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == c["out_text"]
+
+
+def test_cli_slow5_ascii_ranges_and_refusals(models, text_files):
+    c = load_case("dna_default")
+    base = [BIN, "dtw", "--kmer-model", models[6], "--verbose", "0"]
+    files = [c["fasta"], text_files["sp1_dna.blow5"]]
+    parts = [subprocess.run([*base, "--read-range", rg, *files], capture_output=True, timeout=300) for rg in ("0:2", "2:3", "3:")]
+    assert all(p.returncode == 0 for p in parts) and "".join(p.stdout.decode() for p in parts) == c["out_text"]
+    bad = subprocess.run([*base, "--gpu-parse", *files], capture_output=True, timeout=120)
+    assert bad.returncode != 0 and "parsed on the host threads" in bad.stderr.decode()
+    cut = files[1] + ".cut"
+    open(cut, "w").write(open(files[1]).read()[:-1])  # the last newline gone
+    bad = subprocess.run([*base, c["fasta"], cut], capture_output=True, timeout=120)
+    assert bad.returncode != 0 and "newline" in bad.stderr.decode()
+
+
 @pytest.mark.parametrize("stage", ["--host-events", "--gpu-parse"])
 @pytest.mark.parametrize("name", ["dna_default", "dna_from_end", "rna_default", "rna_full_ref_dtw_std", "dna_sam", "rna_sam", "rna_q2000_sam", "rna_q2500", "rna_q4200_full_sam"])
 def test_cli_host_events_path(name, stage, models):

@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--record-press", choices=["none", "zlib"], default=None, help="record compression alone")
     ap.add_argument("--signal-press", choices=["none", "svb-zd"], default=None, help="signal compression alone")
     ap.add_argument("--jobs", type=int, default=1, help="worker processes (zlib of every record is what takes the time)")
+    ap.add_argument("--ascii", action="store_true", help="write SLOW5 ASCII (the text twin of the format; doubles with repr(), so they read back exactly)")
+    ap.add_argument("--keep-ids", action="store_true", help="with --ascii --copies 1: the reads keep their ids (no _0 suffix)")
+    ap.add_argument("--aux", type=int, default=0, help="with --ascii: that many auxiliary columns (uint64_t, value = the copy index)")
     a = ap.parse_args()
     f = S.Blow5File(a.src)
     reads = list(f)
@@ -67,6 +70,24 @@ def main():
     text = "".join(f"@{k}\t{v}\n" for k, v in attrs)
     text += "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
     text += "#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    if a.ascii:
+        with open(a.dst, "w") as out:
+            out.write("#slow5_version\t0.2.0\n#num_read_groups\t1\n" + "".join(f"@{k}\t{v}\n" for k, v in attrs))
+            out.write("#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*" + "\tuint64_t" * a.aux + "\n")
+            out.write("#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal"
+                      + "".join(f"\taux{i}" for i in range(a.aux)) + "\n")
+
+            def num(x):  # slow5lib takes digits, '.' and '-' only: no exponent, and "8192" rather than "8192.0" as slow5tools prints it
+                t = repr(float(x))
+                assert "e" not in t and "n" not in t, t
+                return t[:-2] if t.endswith(".0") else t
+            sigs = [",".join(map(str, raw.tolist())) for _, _, raw in reads]
+            for c in range(a.copies):
+                for (rid, meta, raw), sig in zip(reads, sigs):
+                    out.write((rid if a.keep_ids and a.copies == 1 else f"{rid}_{c}") + f"\t0\t{num(meta['digitisation'])}\t{num(meta['offset'])}\t{num(meta['range'])}\t"
+                              f"{num(meta['sampling_rate'])}\t{len(raw)}\t{sig}" + f"\t{c}" * a.aux + "\n")
+        print(f"{a.dst}: {a.copies * len(reads)} reads, {os.path.getsize(a.dst) / 1e6:.1f} MB (SLOW5 ASCII)")
+        return
     rec_zlib = (a.record_press == "zlib") if a.record_press else a.compress
     sig_svb = (a.signal_press == "svb-zd") if a.signal_press else a.compress
     hdr = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1 if rec_zlib else 0]) + struct.pack("<I", 1) + bytes([1 if sig_svb else 0])
