@@ -328,6 +328,9 @@ int supervise_ranks(Opt &o, double t0) {
     fflush(stdout);
     fflush(stderr);
     const int threads_each = std::max(1, o.threads / G);
+    if (threads_each < 4 && o.verbosity >= 1)  // (a rank's host stages -- inflating and decoding its records -- want a GPU's worth of cores)
+        fprintf(stderr, "[sigfish-amd] WARNING: -t %d over %d ranks leaves %d host thread(s) per rank; the host stages of a rank scale to about 16 (-t %d)\n",
+                o.threads, G, threads_each, 16 * G);
     const pid_t supervisor = getpid();
     for (int r = 0; r < G; ++r) {
         int pfd[2] = {-1, -1};
