@@ -225,6 +225,12 @@ def test_cli_ranks_report_and_failures(models, tmp_path):
                              capture_output=True, timeout=300)
     assert spilled.returncode == 0 and spilled.stdout.decode() == c["out_text"], spilled.stderr.decode()
     assert [l[2] for l in re.findall(r"rank (\d)/2 \(([^)]*)\): done after [0-9.]+ sec, (\d+) bytes", spilled.stderr.decode())] == [l[2] for l in lines]
+    # -o FILE: the ranks and the supervisor share the one open file (rank 0 writes first, the gathered output follows)
+    out = str(tmp_path / "ranks.paf")
+    to_file = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "0", "--ranks", "3", "-o", out, c["fasta"], c["blow5"]], capture_output=True, timeout=300)
+    assert to_file.returncode == 0 and to_file.stdout == b"" and open(out).read() == c["out_text"], to_file.stderr.decode()
+    few = subprocess.run([BIN, "dtw", "--kmer-model", models[6], "--verbose", "1", "--ranks", "3", "-t", "3", c["fasta"], c["blow5"]], capture_output=True, timeout=300)
+    assert few.returncode == 0 and few.stdout.decode() == c["out_text"] and "1 host thread(s) per rank" in few.stderr.decode()
     for extra, msg in ((["--ranks", "2", "--shard", "0/2"], "cannot be combined"), (["--ranks", "2", "--read-range", "0:3"], "cannot be combined"),
                        (["--shard", "2/2"], "0 <= r < G"), (["--read-range", "5"], "A:B"), (["--ranks", "0"], "1..64"),
                        (["--ranks", "2", "--debug-break", "1"], "--ranks 1")):
