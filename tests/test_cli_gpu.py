@@ -47,9 +47,9 @@ def text_files(tmp_path_factory):
     import sys
     d = tmp_path_factory.mktemp("slow5")
     out = {}
-    for name, aux in (("sp1_dna", 0), ("sequin_rna", 2)):
+    for sub, name, aux in (("data", "sp1_dna", 0), ("data", "sequin_rna", 2), ("random", "rnd_dna", 1), ("random", "rnd_rna", 0), ("random", "rnd_dnalong", 0)):
         out[name + ".blow5"] = str(d / (name + ".slow5"))
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, "data", name + ".blow5"), out[name + ".blow5"],
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_blow5.py"), os.path.join(GOLD, sub, name + ".blow5"), out[name + ".blow5"],
                         "--copies", "1", "--ascii", "--keep-ids", "--aux", str(aux)], check=True, capture_output=True)
     return out
 
@@ -67,6 +67,17 @@ def test_cli_reads_slow5_ascii(name, extra, models, text_files):
     r = subprocess.run(cmd, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()
     assert r.stdout.decode() == c["out_text"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--ranks", "3", "-K", "7"]])
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(GOLD, "random", "*.args"))))
+def test_cli_reads_slow5_ascii_random_goldens(name, extra, models, text_files):
+    """the 40-read random-signal files (negative samples, ragged lengths) as text"""
+    k, fasta, blow5, *args = open(os.path.join(GOLD, "random", name + ".args")).read().split("\n")
+    cmd = [BIN, "dtw", "--kmer-model", models[int(k)], "--verbose", "0", *args, *extra, os.path.join(GOLD, "data", fasta), text_files[blow5]]
+    r = subprocess.run(cmd, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == open(os.path.join(GOLD, "random", name + ".out")).read()
 
 
 def test_cli_slow5_ascii_ranges_and_refusals(models, text_files):
